@@ -1,0 +1,108 @@
+/*
+ * afc_oracle.h -- CPU restatement of the reference's Lilypad 2-D BDIM hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle (and the `cpu_baseline`
+ * "port" timed by bench.py).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product path (rlfluidcontrol_amd/) never
+ * links, imports or calls anything in this directory.
+ *
+ * Every function follows one reference function literally (float32 arithmetic, Java
+ * evaluation order, no FMA contraction, sin/cos/sqrt evaluated in double then
+ * narrowed, loop orders as written).  Citations are file:line relative to
+ * /root/reference/clientLilypad/.
+ *
+ * Parity pinning: the reference ships no tests; the oracle is pinned against
+ *   (1) the reference-authored checkpoint saved/init/init.bdim (invariants +
+ *       continuity run, tests/test_oracle_init_bdim.py),
+ *   (2) the analytic known-answer tests in the reference's doc comments
+ *       (PoissonMatrix.pde:17-31, Body.pde:18-28, MG.pde:8-26).
+ * The reference itself (Processing/Java) cannot run here (no JVM), so forces and
+ * vorticity beyond (1)-(2) are "restatement-derived": see DESIGN.md.
+ */
+#ifndef AFC_ORACLE_H
+#define AFC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Oracle Oracle;
+
+/* AFCCylinder ctor, AFCCylinder.pde:11-42 (without resume). */
+Oracle *orc_create(int resolution, int Re, float dR, float gR, float theta,
+                   float dtReal, int xLengths, int yLengths);
+void orc_destroy(Oracle *o);
+
+int orc_n(const Oracle *o);  /* array size in x incl. ghosts (BDIM.n) */
+int orc_m(const Oracle *o);  /* array size in y incl. ghosts (BDIM.m) */
+float orc_dt(const Oracle *o);
+float orc_nu(const Oracle *o);
+float orc_t(const Oracle *o);       /* AFCCylinder.t */
+float orc_flow_t(const Oracle *o);  /* BDIM.t */
+void orc_set_t(Oracle *o, float t);
+
+/* state access, reference layout a[i*m+j] (i = x index, slow) */
+void orc_set_state(Oracle *o, const float *u, const float *v, const float *p);
+void orc_get_state(const Oracle *o, float *u, float *v, float *p);
+
+/* BDIM.resume / BDIM.write, BDIM.pde:226-251 */
+int orc_resume(Oracle *o, const char *path);
+int orc_write(const Oracle *o, const char *path);
+
+/* AFCCylinder.update2, AFCCylinder.pde:45-61.  force[2] = (Fx,Fy) (already negated),
+ * iters[2] / resid[2] = MG iteration count and L_inf residual of the two solves. */
+void orc_update2(Oracle *o, float xi1_m, float xi2_m, float *force, int *iters,
+                 float *resid);
+
+/* coefficient fields after get_coeffs (BDIM.pde:132-196).  which:
+ * 0 del.x 1 del.y 2 del1.x 3 del1.y 4 wnx.x 5 wnx.y 6 wny.x 7 wny.y 8 ub.x 9 ub.y
+ * 10 distance.x 11 distance.y 12 c.x 13 c.y */
+void orc_get_coeff(const Oracle *o, int which, float *out);
+/* re-run get_coeffs with the given rotation increments (for ub tests) */
+void orc_refresh_coeffs(Oracle *o, float dphi1, float dphi2);
+/* per-body weights at a point (BodyUnion.get_weights, BodyUnion.pde:145-156) */
+void orc_weights(const Oracle *o, float x, float y, float *w3);
+
+/* VectorField.curl, VectorField.pde:78-87 */
+void orc_vorticity(const Oracle *o, float *out);
+/* SaveScalar.addData03 probes, SaveScalar.pde:61-72 */
+void orc_probes(const Oracle *o, int num, float *out);
+/* Body.pressForce of body 0, negated (AFCCylinder.pde:58) */
+void orc_force(const Oracle *o, float *force);
+
+/* ---- unit-level entry points (known-answer tests) ---- */
+/* PoissonMatrix(lower).times(x): PoissonMatrix.pde:38-64 */
+void orc_poisson_times(int n, int m, const float *lx, const float *ly,
+                       const float *x, float *out);
+/* PoissonMatrix diag/inv */
+void orc_poisson_diag_inv(int n, int m, const float *lx, const float *ly,
+                          float *diag, float *inv);
+/* MG: construct solver MG(A,x,b) and run `nupdate` update() calls (MG.pde:46-66).
+ * x is updated in place, r_out receives the residual; returns tol. */
+float orc_mg_updates(int n, int m, const float *lx, const float *ly, float *x,
+                     const float *b, int nupdate, float *r_out);
+/* MGsolver (MG.pde:30-38): returns iterations used; x in place */
+int orc_mg_solve(int n, int m, const float *lx, const float *ly, float *x,
+                 const float *b, int itmx, float *resid_linf);
+/* one MG.smooth(itmx) on (r,x) at a single level: MG.pde:79-97 */
+void orc_mg_smooth(int n, int m, const float *lx, const float *ly, float *x,
+                   float *r, int itmx);
+/* Field.setBC, Field.pde:209-234 */
+void orc_setbc(int n, int m, float *a, int btype, float bval, int gradientExit);
+/* VectorField.AdvDif, VectorField.pde:170-223: (fx,fy) advanced in place */
+void orc_advdif(int n, int m, float *fx, float *fy, const float *u0x,
+                const float *u0y, float dt, float nu);
+/* polygon Body.distance, Body.pde:174-192 (closed polygon, coords CCW) */
+float orc_polygon_distance(int npts, const float *xs, const float *ys, float xc,
+                           float yc, float x, float y);
+/* Field.linear, Field.pde:175-190 */
+float orc_linear(int n, int m, const float *a, int btype, float x0, float y0);
+/* BDIM.delta0 / delta1 (eps=2), BodyUnion.delta0 */
+float orc_delta0(float d);
+float orc_delta1(float d);
+float orc_union_delta0(float d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / round-end driver)")
+
+
+@pytest.fixture(scope="session")
+def init_bdim():
+    """The reference's checkpoint clientLilypad/saved/init/init.bdim as float32 arrays."""
+    z = np.load(os.path.join(GOLDEN, "init_bdim_res24.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle_py
+    oracle_py.build()
+    return oracle_py
