@@ -1,0 +1,171 @@
+/*
+ * afc_env.h -- C ABI of libafc_env.so: the MI355X-native, batched replacement for the
+ * reference's Lilypad 2-D BDIM cylinder-wake environment (one `AFCCylinder` per env).
+ *
+ * Drop-in boundary.  The reference has no FFI on this path: the Processing sketch
+ * (clientLilypad/clientCFD.pde) owns an `AFCCylinder test` object and calls
+ *     test = new AFCCylinder(...)            clientCFD.pde:101, AFCCylinder.pde:11-42
+ *     test.update2()                         clientCFD.pde:37,  AFCCylinder.pde:45-61
+ *     test.force / test.t / test.flow.p      clientCFD.pde:38-42
+ *     flow.resume / flow.write               BDIM.pde:226-251
+ *     dat.addData03(... 32 probes ...)       SaveScalar.pde:61-72
+ *     test.display() -> flow.u.curl()        AFCCylinder.pde:86-90, VectorField.pde:78-87
+ * and talks to the agent by XML-RPC strings "Cl_Cd" -> "a1_a2" (clientCFD.pde:117-133,
+ * server/server.py:114-143).  Each entry point below names the reference member it
+ * replaces; a host program (our Python driver, or a JNI stub in the Processing sketch,
+ * see INTEGRATION.md) binds exactly these symbols.
+ *
+ * Conventions: plain C, no torch types.  All functions return 0 on success or a negative
+ * AFC_E* code; afc_last_error() gives the message for the calling thread's last failure.
+ * Handles are not thread-safe.  Buffers are caller-owned.  By default buffers are HOST
+ * pointers; after afc_set_io_space(env, AFC_MEM_DEVICE) the per-env I/O arrays of
+ * afc_sim_step / afc_agent_step / afc_get_obs ... are DEVICE pointers (e.g. torch tensors'
+ * data_ptr()) and the calls are asynchronous on the handle's stream.
+ * Field layout everywhere is the reference's: a[i*m + j], i = x index (slow), j = y index,
+ * one ghost layer per side, n = 16*res+2, m = 8*res+2 (Field.pde:25,33).
+ */
+#ifndef AFC_ENV_H
+#define AFC_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFC_OK 0
+#define AFC_EINVAL (-1)   /* bad argument / bad config */
+#define AFC_ENODEV (-2)   /* no usable HIP device (the product has NO CPU fallback) */
+#define AFC_EHIP (-3)     /* HIP runtime error */
+#define AFC_EIO (-4)      /* file error */
+#define AFC_ESTATE (-5)   /* call not valid in this state */
+#define AFC_EDIVERGED (-6) /* NaN/Inf detected in an env (reported, env is flagged) */
+
+#define AFC_MEM_HOST 0
+#define AFC_MEM_DEVICE 1
+
+/* which field for afc_get_field / afc_set_field */
+#define AFC_FIELD_U 0    /* u.x, BDIM.u.x */
+#define AFC_FIELD_V 1    /* u.y */
+#define AFC_FIELD_P 2    /* p */
+#define AFC_FIELD_VORT 3 /* VectorField.curl(), VectorField.pde:78-87 (read only) */
+
+/* static coefficient arrays for afc_get_static (parity tests compare them with the oracle) */
+#define AFC_STATIC_DELX 0
+#define AFC_STATIC_DELY 1
+#define AFC_STATIC_DEL1X 2
+#define AFC_STATIC_DEL1Y 3
+#define AFC_STATIC_WNXX 4 /* wnx.x */
+#define AFC_STATIC_WNXY 5 /* wnx.y */
+#define AFC_STATIC_WNYX 6 /* wny.x */
+#define AFC_STATIC_WNYY 7 /* wny.y */
+#define AFC_STATIC_CX 8   /* c.x = del.x*dt */
+#define AFC_STATIC_CY 9
+#define AFC_STATIC_W1X 10 /* BodyUnion weight of control cylinder 1 at u points */
+#define AFC_STATIC_W2X 11
+#define AFC_STATIC_W1Y 12
+#define AFC_STATIC_W2Y 13
+
+typedef struct afc_env afc_env;
+
+/* Mirrors the constants the reference hard-codes in clientCFD.pde:5-14,94-96 and
+ * AFCCylinder.pde:11-34.  afc_default_config() fills the reference-native values. */
+typedef struct afc_config {
+  int32_t resolution;   /* clientCFD.pde:14  (24); grid = 16*res x 8*res, D = res */
+  int32_t x_lengths;    /* clientCFD.pde:94  (16) */
+  int32_t y_lengths;    /* clientCFD.pde:94  (8)  */
+  int32_t reynolds;     /* clientCFD.pde:94  (500); nu = D/Re */
+  float t_step;         /* clientCFD.pde:9   tStep = .0075; dt = tStep*res */
+  float dR;             /* clientCFD.pde:95  .125 */
+  float gR;             /* clientCFD.pde:95  .2 */
+  float theta;          /* clientCFD.pde:96  PI/3 */
+  float act_scale;      /* clientCFD.pde:53-54 xi_m = 5*xi */
+  int32_t substeps;     /* clientCFD.pde:12  callLearn = 16 */
+  float init_time;      /* clientCFD.pde:6   initTime = 1 */
+  float end_time;       /* clientCFD.pde:5   Time = 50 */
+  int32_t num_envs;     /* batch of independent AFCCylinder instances */
+  int32_t device;       /* HIP device ordinal */
+  int32_t mg_max_iters; /* VectorField.pde:135  MGsolver(20, ...) */
+  int32_t carry_quirk;  /* 1: keep the Cd/Cl carry of clientCFD.pde:41-47 (reference behaviour) */
+  float reward_penalty; /* server.py:64  0.186756 */
+  int32_t reserved[7];
+} afc_config;
+
+/* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */
+int afc_default_config(afc_config *cfg);
+
+/* new AFCCylinder(...) x num_envs (AFCCylinder.pde:11-42 with isResume=false): free stream
+ * u=(1,0), p=0, t=0.  Builds the static geometry/coefficient fields on the host with Java
+ * float semantics, uploads them, allocates per-env state in HBM. */
+int afc_create(const afc_config *cfg, afc_env **out);
+int afc_destroy(afc_env *env);
+const char *afc_last_error(void);
+
+/* array sizes incl. ghosts (BDIM.n, BDIM.m) and derived constants */
+int afc_dims(const afc_env *env, int32_t *n, int32_t *m);
+int afc_num_envs(const afc_env *env);
+int afc_num_levels(const afc_env *env); /* multigrid levels (MG.pde:99-106) */
+float afc_dt(const afc_env *env);
+
+int afc_set_io_space(afc_env *env, int space);  /* AFC_MEM_HOST | AFC_MEM_DEVICE */
+int afc_set_stream(afc_env *env, void *hip_stream); /* hipStream_t; NULL = default stream */
+int afc_synchronize(afc_env *env);
+
+/* BDIM.resume (BDIM.pde:239-251): parse a reference .bdim text checkpoint and make it the
+ * RESET STATE of every env (AFCCylinder.pde:35-37); also loads it into all envs now. */
+int afc_load_state_bdim(afc_env *env, const char *path);
+/* same, from arrays in reference layout [n*m] (u, v, p) */
+int afc_set_reset_state(afc_env *env, const float *u, const float *v, const float *p);
+/* BDIM.write (BDIM.pde:226-237) for one env */
+int afc_save_state_bdim(afc_env *env, int env_idx, const char *path);
+
+/* setUpNewSim (clientCFD.pde:93-114): envs with mask[e]!=0 (all if mask==NULL) restart from
+ * the reset state with t=0, xi=0.  The averaging window (callLearn, Cd, Cl) is cleared too
+ * unless carry_quirk is set (the reference leaks it across episodes). */
+int afc_reset(afc_env *env, const uint8_t *mask);
+
+/* AFCCylinder.update2 (AFCCylinder.pde:45-61) for every env:
+ * xi_m [E,2] = (xi1_m, xi2_m) rotation rates (already scaled), force [E,2] = test.force. */
+int afc_sim_step(afc_env *env, const float *xi_m, float *force);
+
+/* One agent interaction = the body of draw() (clientCFD.pde:35-56) repeated until the next
+ * action request: action [E,2] in [-1,1] -> xi, xi_m = act_scale*xi; sim-steps with force
+ * averaging after t>init_time; returns obs [E,2] = (Cl, Cd) exactly as sent over XML-RPC,
+ * reward [E] = -Cd - penalty*sum|a|^3 (server.py:61-65), done [E] = (t >= end_time).
+ * nsteps_out (may be NULL) [E] = sim-steps executed for each env. */
+int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
+                   uint8_t *done, int32_t *nsteps_out);
+
+/* per-env scalars: t = AFCCylinder.t [E] */
+int afc_get_time(afc_env *env, float *t);
+/* MG iterations of the last two pressure solves [E,2] and their L_inf residual [E,2]
+ * (the reference prints these, MG.pde:36) */
+int afc_get_solver_stats(afc_env *env, int32_t *iters, float *resid);
+/* diverged flag per env [E] (NaN/Inf guard; absent in the reference) */
+int afc_get_diverged(afc_env *env, uint8_t *flags);
+
+/* field access for one env, reference layout [n*m]; host pointers always */
+int afc_get_field(afc_env *env, int env_idx, int which, float *out);
+int afc_set_field(afc_env *env, int env_idx, int which, const float *in);
+/* SaveScalar.addData03 probes (SaveScalar.pde:61-72): out [E,num] pressure at num points on
+ * the main cylinder surface */
+int afc_get_probes(afc_env *env, int num, float *out);
+/* static coefficient arrays (host pointer, [n*m]); level>0 only for CX/CY (= MG lower.x/.y)
+ * and returns the coarse arrays [n_l*m_l] */
+int afc_get_static(afc_env *env, int which, int level, float *out);
+int afc_level_dims(const afc_env *env, int level, int32_t *n, int32_t *m);
+
+/* --- unit-level device entry points (parity tests drive single operators through the same
+ * kernels the step uses; all pointers HOST, reference layout) --- */
+/* VectorField.AdvDif (VectorField.pde:170-179) on env 0's geometry: (fx,fy) in/out */
+int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const float *u0y);
+/* MGsolver(itmx, PoissonMatrix(c), x, b) (MG.pde:30-38) with the env's own coefficient
+ * hierarchy: x in/out, returns iterations in *iters */
+int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, float *resid_linf);
+/* Field.setBC of the velocity pair (Field.pde:209-234; u.x has gradientExit) */
+int afc_op_setbc_u(afc_env *env, float *ux, float *uy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFC_ENV_H */

@@ -1,0 +1,827 @@
+// afc_env.hip -- libafc_env.so: C ABI (include/afc_env.h) + kernels for the batched BDIM
+// cylinder-wake environment on MI355X (gfx950).  No CPU fallback: every compute entry point
+// fails with AFC_ENODEV when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/afc_env.h"
+#include "bdim_device.h"
+#include "geometry.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(AFC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+using afc::EnvScalars;
+using afc::kThreads;
+using afc::StepParams;
+
+// ---------------- kernels ----------------
+__global__ __launch_bounds__(afc::kThreads) void k_sim_step(StepParams P, const float *__restrict__ xi_m,
+                                                            float *__restrict__ force) {
+  __shared__ double sm[afc::kThreads];
+  __shared__ afc::ShBcast sh;
+  const size_t e = blockIdx.x;
+  const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
+  afc::sim_step(P, e, a, b, sm, &sh);
+  if (threadIdx.x == 0) {
+    EnvScalars &s = P.sc[e];
+    s.xi1_m = a;
+    s.xi2_m = b;
+    s.t += P.dt / P.resolution;  // AFCCylinder.pde:56
+    s.force_x = sh.fx;
+    s.force_y = sh.fy;
+    s.iters[0] = sh.it0;
+    s.iters[1] = sh.it1;
+    s.resid[0] = sh.r0;
+    s.resid[1] = sh.r1;
+    s.sim_steps += 1;
+    if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
+    if (force) {
+      force[2 * e] = sh.fx;
+      force[2 * e + 1] = sh.fy;
+    }
+  }
+}
+
+// The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
+__global__ __launch_bounds__(afc::kThreads) void k_agent_step(StepParams P, const float *__restrict__ action,
+                                                              float *__restrict__ obs, float *__restrict__ reward,
+                                                              uint8_t *__restrict__ done, int *__restrict__ nsteps,
+                                                              int max_steps) {
+  __shared__ double sm[afc::kThreads];
+  __shared__ afc::ShBcast sh;
+  const size_t e = blockIdx.x;
+  EnvScalars s = P.sc[e];  // every thread keeps an identical private copy (uniform control flow)
+  const float a1 = action[2 * e], a2 = action[2 * e + 1];
+  s.xi1 = a1;  // clientCFD.pde:51-54
+  s.xi2 = a2;
+  s.xi1_m = P.act_scale * s.xi1;
+  s.xi2_m = P.act_scale * s.xi2;
+  int steps = 0;
+  bool got = false;
+  while (steps < max_steps) {
+    if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
+    afc::sim_step(P, e, s.xi1_m, s.xi2_m, sm, &sh);
+    ++steps;
+    s.t += P.dt / P.resolution;
+    s.force_x = sh.fx;
+    s.force_y = sh.fy;
+    s.iters[0] = sh.it0;
+    s.iters[1] = sh.it1;
+    s.resid[0] = sh.r0;
+    s.resid[1] = sh.r1;
+    s.sim_steps += 1;
+    if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
+    if (s.t > P.init_time) {  // clientCFD.pde:39-47
+      s.callLearn--;
+      s.Cd += sh.fx;
+      s.Cl += sh.fy;
+      if (s.callLearn <= 0) {
+        s.callLearn = P.substeps;
+        s.Cd = s.Cd / s.callLearn * 2 / P.resolution;
+        s.Cl = s.Cl / s.callLearn * 2 / P.resolution;
+        s.obs_cl = s.Cl;
+        s.obs_cd = s.Cd;
+        if (!P.carry_quirk) {
+          s.Cd = 0.f;
+          s.Cl = 0.f;
+        }
+        got = true;
+        break;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    P.sc[e] = s;
+    obs[2 * e] = s.obs_cl;  // wire order is Cl then Cd (clientCFD.pde:120)
+    obs[2 * e + 1] = s.obs_cd;
+    const float aa1 = afc::jabs(a1), aa2 = afc::jabs(a2);
+    reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
+    done[e] = (!(s.t < P.end_time)) ? 1 : 0;
+    if (nsteps) nsteps[e] = steps;
+    (void)got;
+  }
+}
+
+__global__ void k_reset(StepParams P, const uint8_t *__restrict__ mask, const float *__restrict__ ru,
+                        const float *__restrict__ rv, const float *__restrict__ rp, int keep_window) {
+  const size_t e = blockIdx.x;
+  if (mask && !mask[e]) return;
+  const size_t eo = e * (size_t)P.Ns;
+  for (int k = threadIdx.x; k < P.N; k += blockDim.x) {
+    P.ux[eo + k] = ru[k];
+    P.uy[eo + k] = rv[k];
+    P.p[eo + k] = rp[k];
+    P.u0x[eo + k] = 0.f;  // BDIM.pde:53
+    P.u0y[eo + k] = 0.f;
+  }
+  if (threadIdx.x == 0) {
+    EnvScalars s = P.sc[e];
+    const int cl = s.callLearn;
+    const float cd = s.Cd, cll = s.Cl;
+    s = EnvScalars{};
+    s.callLearn = P.substeps;
+    if (keep_window) {  // clientCFD.pde:12-13 are sketch globals that setUpNewSim does not reset
+      s.callLearn = cl;
+      s.Cd = cd;
+      s.Cl = cll;
+    }
+    P.sc[e] = s;
+  }
+}
+
+__global__ void k_vorticity(StepParams P, int env_idx, float *__restrict__ out) {  // VectorField.pde:78-87
+  const size_t eo = (size_t)env_idx * P.Ns;
+  const float *x = P.ux + eo, *y = P.uy + eo;
+  const int n = P.n, m = P.m;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.N; k += gridDim.x * blockDim.x) {
+    const int i = k / m, j = k - i * m;
+    float v = 0.f;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) v = x[k - 1] - x[k] + y[k] - y[k - m];
+    out[k] = v;
+  }
+}
+
+__global__ void k_probes(StepParams P, const afc::SampleDev *__restrict__ ps, int num, float *__restrict__ out) {
+  const int e = blockIdx.x;
+  const float *p = P.p + (size_t)e * P.Ns;
+  const int m = P.m;
+  for (int q = threadIdx.x; q < num; q += blockDim.x) {
+    const afc::SampleDev sd = ps[q];
+    const float *a = p + sd.base;
+    float val;
+    if (sd.exact)
+      val = a[0];
+    else
+      val = sd.s * (sd.t * a[m + 1] + (1 - sd.t) * a[m]) + (1 - sd.s) * (sd.t * a[1] + (1 - sd.t) * a[0]);
+    out[(size_t)e * num + q] = val;
+  }
+}
+
+// unit-level operators on env 0 (same device functions as the step)
+__global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
+  afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
+}
+__global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
+  __shared__ double sm[afc::kThreads];
+  afc::phase_setbc_u(P, 0, sm);
+}
+__global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iters, float *linf) {
+  __shared__ double sm[afc::kThreads];
+  // b is staged in fx; x in p.  r = b - A x  (MG.pde:51)
+  const afc::Lv L0 = afc::make_level(P, 0, 0);
+  const int n = P.n, m = P.m;
+  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {
+    const int i = k / m, j = k - i * m;
+    float rv = P.fx[k];  // b.minus(A.times(x)): ghosts of A x are 0 -> r ghost = b ghost
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float lw = L0.lx[k], le = L0.lx[k + m], ls = L0.ly[k], ln = L0.ly[k + 1];
+      const float diag = -(lw + le + ls + ln);
+      const float *p = P.p;
+      rv = P.fx[k] - (p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln);
+    }
+    P.r[k] = rv;
+  }
+  __syncthreads();
+  float l;
+  const int it = afc::mg_solve(P, 0, sm, &l);
+  if (threadIdx.x == 0) {
+    *iters = it;
+    *linf = l;
+  }
+}
+
+}  // namespace
+
+// ---------------- host side ----------------
+struct afc_env {
+  afc_config cfg;
+  afc::CaseParams cp;
+  afc::StaticFields sf;
+  StepParams P;
+  hipStream_t stream = nullptr;
+  int io_space = AFC_MEM_HOST;
+  int E = 0;
+  std::vector<void *> allocs;
+  float *rs_u = nullptr, *rs_v = nullptr, *rs_p = nullptr;  // reset state (device)
+  float reset_flow_t = 0, reset_flow_dt = 0;
+  // device staging for host-space I/O
+  float *d_in = nullptr, *d_f2 = nullptr, *d_f1 = nullptr;
+  uint8_t *d_u8 = nullptr;
+  int32_t *d_i32 = nullptr;
+  std::vector<int> level_off;
+  afc::SampleDev *d_probes = nullptr;
+  int n_probes = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(afc_env *env, T **p, size_t count) {
+  void *q = nullptr;
+  HIP_TRY(hipMalloc(&q, count * sizeof(T)));
+  env->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return AFC_OK;
+}
+template <typename T>
+int dev_upload(afc_env *env, const T **p, const std::vector<T> &h) {
+  T *q = nullptr;
+  int rc = dev_alloc(env, &q, h.size());
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return AFC_OK;
+}
+
+int check_env(const afc_env *env) {
+  if (!env) return fail(AFC_EINVAL, "afc: null env handle");
+  return AFC_OK;
+}
+
+afc::SampleDev to_dev(const afc::PressSample &s, int m) {
+  afc::SampleDev d;
+  d.base = s.i * m + s.j;
+  d.s = s.s;
+  d.t = s.t;
+  d.exact = s.exact;
+  return d;
+}
+
+int launch_check(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AFC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  return AFC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *afc_last_error(void) { return g_err.c_str(); }
+
+int afc_default_config(afc_config *cfg) {
+  if (!cfg) return fail(AFC_EINVAL, "afc_default_config: null");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->resolution = 24;
+  cfg->x_lengths = 16;
+  cfg->y_lengths = 8;
+  cfg->reynolds = 500;
+  cfg->t_step = 0.0075f;
+  cfg->dR = 0.125f;
+  cfg->gR = 0.2f;
+  cfg->theta = 3.14159265358979323846f / 3;  // PI/3 in float (clientCFD.pde:96)
+  cfg->act_scale = 5.f;
+  cfg->substeps = 16;
+  cfg->init_time = 1.f;
+  cfg->end_time = 50.f;
+  cfg->num_envs = 1;
+  cfg->device = 0;
+  cfg->mg_max_iters = 20;
+  cfg->carry_quirk = 0;
+  cfg->reward_penalty = (float)(3.14159265358979323846 * (1.0 / 8) * 0.0097 * (3.66 * 3.66 * 3.66));
+  return AFC_OK;
+}
+
+int afc_create(const afc_config *cfg, afc_env **out) {
+  if (!cfg || !out) return fail(AFC_EINVAL, "afc_create: null argument");
+  *out = nullptr;
+  if (cfg->num_envs < 1) return fail(AFC_EINVAL, "afc_create: num_envs must be >= 1");
+  if (cfg->substeps < 1 || cfg->mg_max_iters < 1) return fail(AFC_EINVAL, "afc_create: substeps/mg_max_iters");
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev < 1)
+    return fail(AFC_ENODEV, "afc_create: no HIP device available (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(AFC_EINVAL, "afc_create: device ordinal out of range");
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  afc_env *env = new afc_env();
+  env->cfg = *cfg;
+  env->E = cfg->num_envs;
+  env->cp.resolution = cfg->resolution;
+  env->cp.x_lengths = cfg->x_lengths;
+  env->cp.y_lengths = cfg->y_lengths;
+  env->cp.reynolds = cfg->reynolds;
+  env->cp.t_step = cfg->t_step;
+  env->cp.dR = cfg->dR;
+  env->cp.gR = cfg->gR;
+  env->cp.theta = cfg->theta;
+  try {
+    env->sf = afc::build_static(env->cp);
+  } catch (const std::exception &ex) {
+    std::string msg = ex.what();
+    delete env;
+    return fail(AFC_EINVAL, msg);
+  }
+  const afc::StaticFields &sf = env->sf;
+  if ((int)sf.levels.size() > afc::kMaxLevels) {
+    delete env;
+    return fail(AFC_EINVAL, "afc_create: too many multigrid levels");
+  }
+  StepParams &P = env->P;
+  memset(&P, 0, sizeof(P));
+  P.n = sf.n;
+  P.m = sf.m;
+  P.N = sf.n * sf.m;
+  P.Ns = (P.N + 63) / 64 * 64;
+  P.nlev = (int)sf.levels.size();
+  P.dt = sf.dt;
+  P.nu = sf.nu;
+  P.D = sf.D;
+  P.dR = cfg->dR;
+  P.mg_tol = sf.mg_tol;
+  P.mg_max_iters = cfg->mg_max_iters;
+  P.resolution = cfg->resolution;
+  P.act_scale = cfg->act_scale;
+  P.init_time = cfg->init_time;
+  P.end_time = cfg->end_time;
+  P.reward_penalty = cfg->reward_penalty;
+  P.substeps = cfg->substeps;
+  P.carry_quirk = cfg->carry_quirk;
+
+  int rc = AFC_OK;
+#define UP(field) if (!rc) rc = dev_upload(env, &P.field, sf.field)
+  UP(delx); UP(dely); UP(del1x); UP(del1y); UP(wnxx); UP(wnxy); UP(wnyx); UP(wnyy); UP(cx); UP(cy);
+  UP(w1x); UP(w2x); UP(ry1x); UP(ry2x); UP(w1y); UP(w2y); UP(rx1y); UP(rx2y);
+  UP(seg_l); UP(seg_nx); UP(seg_ny);
+#undef UP
+  // multigrid hierarchy, all levels concatenated
+  std::vector<float> lx, ly, inv;
+  int coff = 0, soff = 0;
+  for (int l = 0; l < P.nlev; ++l) {
+    const afc::MGLevel &L = sf.levels[l];
+    P.lev[l].n = L.n;
+    P.lev[l].m = L.m;
+    P.lev[l].coef_off = coff;
+    P.lev[l].scratch_off = (l == 0) ? 0 : soff;
+    const int cnt = L.n * L.m;
+    lx.insert(lx.end(), L.lx.begin(), L.lx.end());
+    ly.insert(ly.end(), L.ly.begin(), L.ly.end());
+    inv.insert(inv.end(), L.inv.begin(), L.inv.end());
+    const int pad = (64 - cnt % 64) % 64;
+    lx.insert(lx.end(), pad, 0.f);
+    ly.insert(ly.end(), pad, 0.f);
+    inv.insert(inv.end(), pad, 1.f);
+    coff += cnt + pad;
+    if (l >= 1) soff += cnt + pad;
+  }
+  P.Cs = 4 * ((soff + 63) / 64 * 64);
+  if (!rc) rc = dev_upload(env, &P.mg_lx, lx);
+  if (!rc) rc = dev_upload(env, &P.mg_ly, ly);
+  if (!rc) rc = dev_upload(env, &P.mg_inv, inv);
+  std::vector<afc::SampleDev> fs;
+  for (const auto &s : sf.force_samples) fs.push_back(to_dev(s, sf.m));
+  P.nseg = (int)fs.size();
+  if (!rc) rc = dev_upload(env, &P.fs, fs);
+
+  const size_t E = (size_t)env->E;
+  float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
+  for (float **f : fields) {
+    if (!rc) rc = dev_alloc(env, f, E * P.Ns);
+    if (!rc && hipMemset(*f, 0, E * P.Ns * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  }
+  if (!rc) rc = dev_alloc(env, &P.coarse, E * (size_t)P.Cs);
+  if (!rc && hipMemset(P.coarse, 0, E * (size_t)P.Cs * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  if (!rc) rc = dev_alloc(env, &P.sc, E);
+  if (!rc && hipMemset(P.sc, 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  if (!rc) rc = dev_alloc(env, &env->rs_u, (size_t)P.Ns);
+  if (!rc) rc = dev_alloc(env, &env->rs_v, (size_t)P.Ns);
+  if (!rc) rc = dev_alloc(env, &env->rs_p, (size_t)P.Ns);
+  if (!rc) rc = dev_alloc(env, &env->d_in, E * 2);
+  if (!rc) rc = dev_alloc(env, &env->d_f2, E * 2);
+  if (!rc) rc = dev_alloc(env, &env->d_f1, E);
+  if (!rc) rc = dev_alloc(env, &env->d_u8, E);
+  if (!rc) rc = dev_alloc(env, &env->d_i32, E * 2);
+  if (rc) {
+    afc_destroy(env);
+    return rc;
+  }
+  // free-stream reset state: new VectorField(n+2,m+2,1,0), p = 0  (BDIM.pde:70-71,54)
+  std::vector<float> ones(P.N, 1.f), zeros(P.N, 0.f);
+  *out = env;
+  rc = afc_set_reset_state(env, ones.data(), zeros.data(), zeros.data());
+  if (rc) {
+    afc_destroy(env);
+    *out = nullptr;
+    return rc;
+  }
+  return AFC_OK;
+}
+
+int afc_destroy(afc_env *env) {
+  if (!env) return AFC_OK;
+  hipSetDevice(env->cfg.device);
+  hipDeviceSynchronize();
+  for (void *p : env->allocs) hipFree(p);
+  delete env;
+  return AFC_OK;
+}
+
+int afc_dims(const afc_env *env, int32_t *n, int32_t *m) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (n) *n = env->P.n;
+  if (m) *m = env->P.m;
+  return AFC_OK;
+}
+int afc_num_envs(const afc_env *env) { return env ? env->E : AFC_EINVAL; }
+int afc_num_levels(const afc_env *env) { return env ? env->P.nlev : AFC_EINVAL; }
+float afc_dt(const afc_env *env) { return env ? env->P.dt : 0.f; }
+int afc_level_dims(const afc_env *env, int level, int32_t *n, int32_t *m) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (level < 0 || level >= env->P.nlev) return fail(AFC_EINVAL, "afc_level_dims: bad level");
+  if (n) *n = env->P.lev[level].n;
+  if (m) *m = env->P.lev[level].m;
+  return AFC_OK;
+}
+
+int afc_set_io_space(afc_env *env, int space) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (space != AFC_MEM_HOST && space != AFC_MEM_DEVICE) return fail(AFC_EINVAL, "afc_set_io_space: bad space");
+  env->io_space = space;
+  return AFC_OK;
+}
+int afc_set_stream(afc_env *env, void *hip_stream) {
+  if (check_env(env)) return AFC_EINVAL;
+  env->stream = static_cast<hipStream_t>(hip_stream);
+  return AFC_OK;
+}
+int afc_synchronize(afc_env *env) {
+  if (check_env(env)) return AFC_EINVAL;
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  return AFC_OK;
+}
+
+int afc_set_reset_state(afc_env *env, const float *u, const float *v, const float *p) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!u || !v || !p) return fail(AFC_EINVAL, "afc_set_reset_state: null array");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  const size_t bytes = (size_t)env->P.N * sizeof(float);
+  HIP_TRY(hipMemcpy(env->rs_u, u, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(env->rs_v, v, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(env->rs_p, p, bytes, hipMemcpyHostToDevice));
+  // a fresh AFCCylinder: callLearn etc. are initialised like the sketch globals
+  hipLaunchKernelGGL(k_reset, dim3(env->E), dim3(256), 0, env->stream, env->P, (const uint8_t *)nullptr, env->rs_u,
+                     env->rs_v, env->rs_p, 0);
+  int rc = launch_check("k_reset");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  return AFC_OK;
+}
+
+int afc_load_state_bdim(afc_env *env, const char *path) {  // BDIM.resume, BDIM.pde:239-251
+  if (check_env(env)) return AFC_EINVAL;
+  if (!path) return fail(AFC_EINVAL, "afc_load_state_bdim: null path");
+  FILE *f = fopen(path, "r");
+  if (!f) return fail(AFC_EIO, std::string("afc_load_state_bdim: cannot open ") + path);
+  const int n = env->P.n, m = env->P.m;
+  std::vector<float> u((size_t)n * m), v((size_t)n * m), p((size_t)n * m);
+  char line[512];
+  bool ok = fgets(line, sizeof line, f) != nullptr;
+  if (ok) env->reset_flow_t = strtof(line, nullptr);
+  ok = ok && fgets(line, sizeof line, f) != nullptr;
+  if (ok) env->reset_flow_dt = strtof(line, nullptr);
+  for (size_t k = 0; ok && k < (size_t)n * m; ++k) {
+    if (!fgets(line, sizeof line, f)) {
+      ok = false;
+      break;
+    }
+    char *q = line;  // Java: float(split(line, ','))
+    u[k] = strtof(q, &q);
+    while (*q == ',' || *q == ' ') ++q;
+    v[k] = strtof(q, &q);
+    while (*q == ',' || *q == ' ') ++q;
+    p[k] = strtof(q, &q);
+  }
+  fclose(f);
+  if (!ok) return fail(AFC_EIO, std::string("afc_load_state_bdim: truncated or malformed file ") + path);
+  return afc_set_reset_state(env, u.data(), v.data(), p.data());
+}
+
+int afc_save_state_bdim(afc_env *env, int env_idx, const char *path) {  // BDIM.write, BDIM.pde:226-237
+  if (check_env(env)) return AFC_EINVAL;
+  if (!path || env_idx < 0 || env_idx >= env->E) return fail(AFC_EINVAL, "afc_save_state_bdim: bad argument");
+  const int N = env->P.N;
+  std::vector<float> u(N), v(N), p(N);
+  int rc = afc_get_field(env, env_idx, AFC_FIELD_U, u.data());
+  if (!rc) rc = afc_get_field(env, env_idx, AFC_FIELD_V, v.data());
+  if (!rc) rc = afc_get_field(env, env_idx, AFC_FIELD_P, p.data());
+  if (rc) return rc;
+  EnvScalars s;
+  HIP_TRY(hipMemcpy(&s, env->P.sc + env_idx, sizeof(s), hipMemcpyDeviceToHost));
+  FILE *f = fopen(path, "w");
+  if (!f) return fail(AFC_EIO, std::string("afc_save_state_bdim: cannot open ") + path);
+  // BDIM.t advances by dt per step (BDIM.pde:106); %.9g round-trips every float32
+  const float flow_t = env->reset_flow_t + (float)s.sim_steps * env->P.dt;
+  fprintf(f, "%.9g\n%.9g\n", flow_t, env->P.dt);
+  for (int k = 0; k < N; ++k) fprintf(f, "%.9g, %.9g, %.9g\n", u[k], v[k], p[k]);
+  fclose(f);
+  return AFC_OK;
+}
+
+int afc_reset(afc_env *env, const uint8_t *mask) {
+  if (check_env(env)) return AFC_EINVAL;
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  const uint8_t *dmask = mask;
+  if (mask && env->io_space == AFC_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(env->d_u8, mask, env->E, hipMemcpyHostToDevice, env->stream));
+    dmask = env->d_u8;
+  }
+  hipLaunchKernelGGL(k_reset, dim3(env->E), dim3(256), 0, env->stream, env->P, dmask, env->rs_u, env->rs_v,
+                     env->rs_p, env->cfg.carry_quirk);
+  int rc = launch_check("k_reset");
+  if (rc) return rc;
+  if (env->io_space == AFC_MEM_HOST) HIP_TRY(hipStreamSynchronize(env->stream));
+  return AFC_OK;
+}
+
+int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!xi_m) return fail(AFC_EINVAL, "afc_sim_step: null xi_m");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  const size_t E = env->E;
+  const float *dxi = xi_m;
+  float *dforce = force;
+  if (env->io_space == AFC_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(env->d_in, xi_m, E * 2 * sizeof(float), hipMemcpyHostToDevice, env->stream));
+    dxi = env->d_in;
+    dforce = env->d_f2;
+  }
+  hipLaunchKernelGGL(k_sim_step, dim3(env->E), dim3(kThreads), 0, env->stream, env->P, dxi, dforce);
+  int rc = launch_check("k_sim_step");
+  if (rc) return rc;
+  if (env->io_space == AFC_MEM_HOST) {
+    if (force)
+      HIP_TRY(hipMemcpyAsync(force, env->d_f2, E * 2 * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+  }
+  return AFC_OK;
+}
+
+int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward, uint8_t *done,
+                   int32_t *nsteps_out) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!action || !obs || !reward || !done) return fail(AFC_EINVAL, "afc_agent_step: null argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  const size_t E = env->E;
+  const bool host = env->io_space == AFC_MEM_HOST;
+  const float *dact = action;
+  float *dobs = obs, *drew = reward;
+  uint8_t *ddone = done;
+  int32_t *dns = nsteps_out;
+  if (host) {
+    HIP_TRY(hipMemcpyAsync(env->d_in, action, E * 2 * sizeof(float), hipMemcpyHostToDevice, env->stream));
+    dact = env->d_in;
+    dobs = env->d_f2;
+    drew = env->d_f1;
+    ddone = env->d_u8;
+    dns = env->d_i32;
+  }
+  // upper bound on sim-steps per call: warm-up (t <= init_time) + one averaging window
+  const float per = env->P.dt / env->cfg.resolution;
+  const int max_steps = (int)(env->cfg.init_time / per) + 2 * env->cfg.substeps + 8;
+  hipLaunchKernelGGL(k_agent_step, dim3(env->E), dim3(kThreads), 0, env->stream, env->P, dact, dobs, drew, ddone,
+                     dns, max_steps);
+  int rc = launch_check("k_agent_step");
+  if (rc) return rc;
+  if (host) {
+    HIP_TRY(hipMemcpyAsync(obs, dobs, E * 2 * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipMemcpyAsync(reward, drew, E * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipMemcpyAsync(done, ddone, E, hipMemcpyDeviceToHost, env->stream));
+    if (nsteps_out)
+      HIP_TRY(hipMemcpyAsync(nsteps_out, dns, E * sizeof(int32_t), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+  }
+  return AFC_OK;
+}
+
+static int fetch_scalars(afc_env *env, std::vector<EnvScalars> &h) {
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  h.resize(env->E);
+  HIP_TRY(hipMemcpy(h.data(), env->P.sc, env->E * sizeof(EnvScalars), hipMemcpyDeviceToHost));
+  return AFC_OK;
+}
+
+int afc_get_time(afc_env *env, float *t) {
+  if (check_env(env) || !t) return fail(AFC_EINVAL, "afc_get_time: bad argument");
+  std::vector<EnvScalars> h;
+  int rc = fetch_scalars(env, h);
+  if (rc) return rc;
+  for (int e = 0; e < env->E; ++e) t[e] = h[e].t;
+  return AFC_OK;
+}
+int afc_get_solver_stats(afc_env *env, int32_t *iters, float *resid) {
+  if (check_env(env)) return AFC_EINVAL;
+  std::vector<EnvScalars> h;
+  int rc = fetch_scalars(env, h);
+  if (rc) return rc;
+  for (int e = 0; e < env->E; ++e) {
+    if (iters) {
+      iters[2 * e] = h[e].iters[0];
+      iters[2 * e + 1] = h[e].iters[1];
+    }
+    if (resid) {
+      resid[2 * e] = h[e].resid[0];
+      resid[2 * e + 1] = h[e].resid[1];
+    }
+  }
+  return AFC_OK;
+}
+int afc_get_diverged(afc_env *env, uint8_t *flags) {
+  if (check_env(env) || !flags) return fail(AFC_EINVAL, "afc_get_diverged: bad argument");
+  std::vector<EnvScalars> h;
+  int rc = fetch_scalars(env, h);
+  if (rc) return rc;
+  for (int e = 0; e < env->E; ++e) flags[e] = h[e].diverged ? 1 : 0;
+  return AFC_OK;
+}
+
+int afc_get_field(afc_env *env, int env_idx, int which, float *out) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!out || env_idx < 0 || env_idx >= env->E) return fail(AFC_EINVAL, "afc_get_field: bad argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t eo = (size_t)env_idx * P.Ns, bytes = (size_t)P.N * sizeof(float);
+  const float *src = nullptr;
+  switch (which) {
+    case AFC_FIELD_U: src = P.ux + eo; break;
+    case AFC_FIELD_V: src = P.uy + eo; break;
+    case AFC_FIELD_P: src = P.p + eo; break;
+    case AFC_FIELD_VORT: {
+      float *tmp = P.fx + eo;  // fx is scratch between steps
+      hipLaunchKernelGGL(k_vorticity, dim3(64), dim3(256), 0, env->stream, P, env_idx, tmp);
+      int rc = launch_check("k_vorticity");
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(env->stream));
+      src = tmp;
+      break;
+    }
+    default: return fail(AFC_EINVAL, "afc_get_field: unknown field");
+  }
+  HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return AFC_OK;
+}
+int afc_set_field(afc_env *env, int env_idx, int which, const float *in) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!in || env_idx < 0 || env_idx >= env->E) return fail(AFC_EINVAL, "afc_set_field: bad argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t eo = (size_t)env_idx * P.Ns;
+  float *dst = nullptr;
+  switch (which) {
+    case AFC_FIELD_U: dst = P.ux + eo; break;
+    case AFC_FIELD_V: dst = P.uy + eo; break;
+    case AFC_FIELD_P: dst = P.p + eo; break;
+    default: return fail(AFC_EINVAL, "afc_set_field: field is read-only or unknown");
+  }
+  HIP_TRY(hipMemcpy(dst, in, (size_t)P.N * sizeof(float), hipMemcpyHostToDevice));
+  return AFC_OK;
+}
+
+int afc_get_probes(afc_env *env, int num, float *out) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (num < 1 || num > 4096 || !out) return fail(AFC_EINVAL, "afc_get_probes: bad argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  if (env->n_probes != num) {
+    std::vector<afc::SampleDev> ps;
+    for (const auto &s : afc::build_probes(env->cp, num)) ps.push_back(to_dev(s, env->P.m));
+    afc::SampleDev *d = nullptr;
+    int rc = dev_alloc(env, &d, ps.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(d, ps.data(), ps.size() * sizeof(afc::SampleDev), hipMemcpyHostToDevice));
+    env->d_probes = d;
+    env->n_probes = num;
+  }
+  float *dout = nullptr;
+  HIP_TRY(hipMalloc(&dout, (size_t)env->E * num * sizeof(float)));
+  hipLaunchKernelGGL(k_probes, dim3(env->E), dim3(64), 0, env->stream, env->P, env->d_probes, num, dout);
+  int rc = launch_check("k_probes");
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(env->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)env->E * num * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(AFC_EHIP, hipGetErrorString(e));
+  }
+  hipFree(dout);
+  return rc;
+}
+
+int afc_get_static(afc_env *env, int which, int level, float *out) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!out) return fail(AFC_EINVAL, "afc_get_static: null out");
+  const afc::StaticFields &sf = env->sf;
+  if (level < 0 || level >= (int)sf.levels.size()) return fail(AFC_EINVAL, "afc_get_static: bad level");
+  const std::vector<float> *src = nullptr;
+  if (level > 0) {
+    if (which == AFC_STATIC_CX) src = &sf.levels[level].lx;
+    else if (which == AFC_STATIC_CY) src = &sf.levels[level].ly;
+    else return fail(AFC_EINVAL, "afc_get_static: only CX/CY exist on coarse levels");
+  } else {
+    switch (which) {
+      case AFC_STATIC_DELX: src = &sf.delx; break;
+      case AFC_STATIC_DELY: src = &sf.dely; break;
+      case AFC_STATIC_DEL1X: src = &sf.del1x; break;
+      case AFC_STATIC_DEL1Y: src = &sf.del1y; break;
+      case AFC_STATIC_WNXX: src = &sf.wnxx; break;
+      case AFC_STATIC_WNXY: src = &sf.wnxy; break;
+      case AFC_STATIC_WNYX: src = &sf.wnyx; break;
+      case AFC_STATIC_WNYY: src = &sf.wnyy; break;
+      case AFC_STATIC_CX: src = &sf.cx; break;
+      case AFC_STATIC_CY: src = &sf.cy; break;
+      case AFC_STATIC_W1X: src = &sf.w1x; break;
+      case AFC_STATIC_W2X: src = &sf.w2x; break;
+      case AFC_STATIC_W1Y: src = &sf.w1y; break;
+      case AFC_STATIC_W2Y: src = &sf.w2y; break;
+      default: return fail(AFC_EINVAL, "afc_get_static: unknown array");
+    }
+  }
+  memcpy(out, src->data(), src->size() * sizeof(float));
+  return AFC_OK;
+}
+
+// ---- unit-level operators (env 0's buffers are used as scratch: state of env 0 is clobbered) ----
+int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const float *u0y) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!fx || !fy || !u0x || !u0y) return fail(AFC_EINVAL, "afc_op_advdif: null argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t bytes = (size_t)P.N * sizeof(float);
+  HIP_TRY(hipMemcpy(P.ux, fx, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(P.uy, fy, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(P.u0x, u0x, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(P.u0y, u0y, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_op_advdif, dim3(1), dim3(kThreads), 0, env->stream, P);
+  int rc = launch_check("k_op_advdif");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  HIP_TRY(hipMemcpy(fx, P.fx, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fy, P.fy, bytes, hipMemcpyDeviceToHost));
+  return AFC_OK;
+}
+
+int afc_op_setbc_u(afc_env *env, float *ux, float *uy) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!ux || !uy) return fail(AFC_EINVAL, "afc_op_setbc_u: null argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t bytes = (size_t)P.N * sizeof(float);
+  HIP_TRY(hipMemcpy(P.ux, ux, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(P.uy, uy, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_op_setbc, dim3(1), dim3(kThreads), 0, env->stream, P);
+  int rc = launch_check("k_op_setbc");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  HIP_TRY(hipMemcpy(ux, P.ux, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(uy, P.uy, bytes, hipMemcpyDeviceToHost));
+  return AFC_OK;
+}
+
+int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, float *resid_linf) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!x || !b) return fail(AFC_EINVAL, "afc_op_mg_solve: null argument");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t bytes = (size_t)P.N * sizeof(float);
+  HIP_TRY(hipMemcpy(P.p, x, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(P.fx, b, bytes, hipMemcpyHostToDevice));
+  int *dit = reinterpret_cast<int *>(env->d_i32);
+  float *dl = env->d_f1;
+  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), 0, env->stream, P, dit, dl);
+  int rc = launch_check("k_op_mg");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  HIP_TRY(hipMemcpy(x, P.p, bytes, hipMemcpyDeviceToHost));
+  int it = 0;
+  float l = 0;
+  HIP_TRY(hipMemcpy(&it, dit, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&l, dl, sizeof(float), hipMemcpyDeviceToHost));
+  if (iters) *iters = it;
+  if (resid_linf) *resid_linf = l;
+  return AFC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+// bdim_device.h -- device side of the batched BDIM step (gfx950).
+//
+// Execution model: ONE WORKGROUP PER ENV, persistent over a whole agent step.  Envs are
+// independent simulations, so no inter-workgroup communication exists anywhere: every
+// reduction (outflow mean, mean pressure, r.r) is workgroup-local and every data-dependent
+// loop (multigrid iterations, episode bookkeeping) is a per-workgroup loop.  With E >= 4 x 256
+// workgroups the latency-bound phases of one env (ordered Gauss-Seidel) overlap the streaming
+// phases of the other envs resident on the same CU.
+//
+// Arithmetic: float32, -ffp-contract=off, the reference's evaluation order (file:line cited at
+// each function).  The only deviations from the reference's bits are the three order-sensitive
+// reductions (Field.sum, the setBC outflow mean, Field.inner), which are tree reductions here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afc {
+
+constexpr int kThreads = 256;    // workgroup size (4 waves)
+constexpr int kMaxLevels = 12;
+
+struct LevelDesc {
+  int n, m;          // array size incl. ghosts
+  int coef_off;      // offset (floats) of this level in mg_lx/mg_ly/mg_inv
+  int scratch_off;   // offset (floats) of this level in the per-env coarse scratch (levels >= 1)
+};
+
+struct SampleDev {
+  int base;  // i*m + j
+  float s, t;
+  int exact;
+};
+
+struct EnvScalars {  // per-env episode state (clientCFD.pde globals + AFCCylinder fields)
+  float t;           // AFCCylinder.t
+  float xi1, xi2;    // test.xi1, test.xi2
+  float xi1_m, xi2_m;
+  int callLearn;     // clientCFD.pde:12
+  float Cd, Cl;      // clientCFD.pde:13 running sums
+  float force_x, force_y;
+  float obs_cl, obs_cd;  // last observation sent
+  int iters[2];
+  float resid[2];
+  int diverged;
+  int sim_steps;     // total since reset
+  float p_shift;     // reserved (deferred mean shift)
+  int pad;
+};
+
+struct StepParams {
+  int n, m, N;       // field dims, N = n*m
+  int Ns;            // per-env stride of a fine field (floats)
+  int Cs;            // per-env stride of the coarse scratch (floats), 4 arrays of Cs/4
+  int nlev;
+  LevelDesc lev[kMaxLevels];
+  float dt, nu, D, dR, mg_tol;
+  int mg_max_iters, resolution;
+  // env-shared static fields (L2/MALL resident)
+  const float *delx, *dely, *del1x, *del1y, *wnxx, *wnxy, *wnyx, *wnyy, *cx, *cy;
+  const float *w1x, *w2x, *ry1x, *ry2x, *w1y, *w2y, *rx1y, *rx2y;
+  const float *mg_lx, *mg_ly, *mg_inv;
+  const SampleDev *fs;
+  const float *seg_l, *seg_nx, *seg_ny;
+  int nseg;
+  // per-env state [E][Ns]
+  float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d;
+  float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
+  EnvScalars *sc;
+  // episode constants
+  float act_scale, init_time, end_time, reward_penalty;
+  int substeps, carry_quirk;
+};
+
+// ---- PApplet float helpers (same semantics as Java's) ----
+__device__ __forceinline__ float jmin(float a, float b) { return (a < b) ? a : b; }
+__device__ __forceinline__ float jmax(float a, float b) { return (a > b) ? a : b; }
+__device__ __forceinline__ float jabs(float a) { return (a < 0) ? -a : a; }
+__device__ __forceinline__ float med3(float a, float b, float c) {  // VectorField.pde:221-223
+  return jmax(jmin(a, b), jmin(jmax(a, b), c));
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- workgroup reductions (fixed tree order => deterministic) ----
+__device__ inline double block_sum_d(double v, double *sm) {
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) sm[t] += sm[t + s];
+    __syncthreads();
+  }
+  double r = sm[0];
+  __syncthreads();
+  return r;
+}
+__device__ inline float block_max_f(float v, double *smd) {
+  float *sm = reinterpret_cast<float *>(smd);
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) sm[t] = jmax(sm[t], sm[t + s]);
+    __syncthreads();
+  }
+  float r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- QUICK advection + diffusion (VectorField.pde:170-223) ----
+// b: the advected component, (bx,by) = velocity pair, all in reference layout with pitch m
+__device__ __forceinline__ float bho(const float *__restrict__ b, int n, int m, int i, int j, int d1, int d2,
+                                     float uf) {  // VectorField.pde:202-219
+  float bf = 0.5f * (b[(i + d1) * m + (j + d2)] + b[i * m + j]);
+  if (d1 * uf < 0) {
+    i += d1;
+    d1 = -d1;
+  }
+  if (d2 * uf < 0) {
+    j += d2;
+    d2 = -d2;
+  }
+  if (i > n - 2 || i < 2 || j > m - 2 || j < 2) return bf;
+  const float bc = b[i * m + j];
+  const float bd = b[(i + d1) * m + (j + d2)];
+  const float bu = b[(i - d1) * m + (j - d2)];
+  bf -= (1.f / 6.f) * (bd - 2 * bc + bu);
+  const float b1 = bu + 10.f * (bc - bu);
+  return med3(bf, bc, med3(bc, bd, b1));
+}
+__device__ __forceinline__ float advdif_x(const float *__restrict__ x, const float *__restrict__ y, int n, int m,
+                                          int i, int j, float nu) {
+  const int k = i * m + j;  // VectorField.pde:183-188 (btype 1)
+  const float uo = 0.5f * (x[k - m] + x[k]);
+  const float ue = 0.5f * (x[k + m] + x[k]);
+  const float vs = 0.5f * (y[k] + y[k - m]);
+  const float vn = 0.5f * (y[k + 1] + y[k - m + 1]);
+  const float adv = ((uo * bho(x, n, m, i, j, -1, 0, uo) - ue * bho(x, n, m, i, j, 1, 0, ue)) +
+                     (vs * bho(x, n, m, i, j, 0, -1, vs) - vn * bho(x, n, m, i, j, 0, 1, vn)));
+  const float dif = x[k + m] + x[k + 1] - 4 * x[k] + x[k - m] + x[k - 1];  // :198-200
+  return adv + nu * dif;
+}
+__device__ __forceinline__ float advdif_y(const float *__restrict__ x, const float *__restrict__ y, int n, int m,
+                                          int i, int j, float nu) {
+  const int k = i * m + j;  // VectorField.pde:189-194 (btype 2)
+  const float uo = 0.5f * (x[k - 1] + x[k]);
+  const float ue = 0.5f * (x[k + m - 1] + x[k + m]);
+  const float vs = 0.5f * (y[k - 1] + y[k]);
+  const float vn = 0.5f * (y[k] + y[k + 1]);
+  const float adv = ((uo * bho(y, n, m, i, j, -1, 0, uo) - ue * bho(y, n, m, i, j, 1, 0, ue)) +
+                     (vs * bho(y, n, m, i, j, 0, -1, vs) - vn * bho(y, n, m, i, j, 0, 1, vn)));
+  const float dif = y[k + m] + y[k + 1] - 4 * y[k] + y[k - m] + y[k - 1];
+  return adv + nu * dif;
+}
+
+// Phase A.  predictor (BDIM.update, BDIM.pde:79-87): u0 = u; F = u; F.AdvDif(u0)
+//           corrector (BDIM.update2, BDIM.pde:89-97): us = u; F = u; F.AdvDif(u0)
+__device__ inline void phase_advdif(const StepParams &P, size_t eo, bool corrector) {
+  const int n = P.n, m = P.m;
+  const float *ux = P.ux + eo, *uy = P.uy + eo;
+  float *savx = (corrector ? P.usx : P.u0x) + eo, *savy = (corrector ? P.usy : P.u0y) + eo;
+  const float *u0x = P.u0x + eo, *u0y = P.u0y + eo;
+  float *fx = P.fx + eo, *fy = P.fy + eo;
+  for (int k = threadIdx.x; k < P.N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    const float cxv = ux[k], cyv = uy[k];
+    float ox = cxv, oy = cyv;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float bx = corrector ? u0x[k] : cxv, by = corrector ? u0y[k] : cyv;
+      ox = advdif_x(ux, uy, n, m, i, j, P.nu) * P.dt + bx;  // VectorField.pde:174-175
+      oy = advdif_y(ux, uy, n, m, i, j, P.nu) * P.dt + by;
+    }
+    savx[k] = cxv;
+    savy[k] = cyv;
+    fx[k] = ox;
+    fy[k] = oy;
+  }
+  __syncthreads();
+}
+
+// body velocity at a u / v point (BDIM.pde:140-149, BodyUnion.pde:84-92, Body.pde:234-240)
+__device__ __forceinline__ float ub_x_at(const StepParams &P, int k, float dphi1, float dphi2) {
+  float v = 0.f;
+  v += 0.f;  // main cylinder: dphi == 0 -> (0 - ry*0)/dt * w0 == 0
+  v += ((0.f - P.ry1x[k] * dphi1) / P.dt) * P.w1x[k];
+  v += ((0.f - P.ry2x[k] * dphi2) / P.dt) * P.w2x[k];
+  return v;
+}
+__device__ __forceinline__ float ub_y_at(const StepParams &P, int k, float dphi1, float dphi2) {
+  float v = 0.f;
+  v += 0.f;
+  v += ((0.f + P.rx1y[k] * dphi1) / P.dt) * P.w1y[k];
+  v += ((0.f + P.rx2y[k] * dphi2) / P.dt) * P.w2y[k];
+  return v;
+}
+
+// Phase B.  BDIM.updateUP lines 118-120 (BDIM.pde): u = del*F - ub*(del-1) + del1*ddn(F-ub)
+__device__ inline void phase_forcing(const StepParams &P, size_t eo, float dphi1, float dphi2) {
+  const int n = P.n, m = P.m;
+  const float *fx = P.fx + eo, *fy = P.fy + eo;
+  float *ux = P.ux + eo, *uy = P.uy + eo;
+  for (int k = threadIdx.x; k < P.N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    const bool interior = (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2);
+    {
+      const float del = P.delx[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
+      float un = del * R - ub * (del + (-1.f));
+      if (interior) {  // VectorField.normalGrad, VectorField.pde:46-54 (ghosts of g are 0)
+        const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
+        const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
+        const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
+        const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
+        const float g = 0.5f * (P.wnxx[k] * (dE - dW) + P.wnyx[k] * (dN - dS));
+        un = un + P.del1x[k] * g;
+      }
+      ux[k] = un;
+    }
+    {
+      const float del = P.dely[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
+      float un = del * R - ub * (del + (-1.f));
+      if (interior) {
+        const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
+        const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
+        const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
+        const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
+        const float g = 0.5f * (P.wnxy[k] * (dE - dW) + P.wnyy[k] * (dN - dS));
+        un = un + P.del1y[k] * g;
+      }
+      uy[k] = un;
+    }
+  }
+  __syncthreads();
+}
+
+// Phase C.  u.setBC() (Field.pde:209-234): u.x is btype 1 with gradientExit (bval 1),
+// u.y is btype 2 (bval 0).  Statement order of the reference is preserved: x-loop, y-loop,
+// then the outflow-mean correction.  The mean is a tree sum (reference: sequential float).
+__device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
+  const int n = P.n, m = P.m;
+  float *ux = P.ux + eo, *uy = P.uy + eo;
+  double part = 0;
+  for (int j = threadIdx.x; j < m; j += kThreads) {
+    ux[j] = ux[m + j];
+    const float o = ux[(n - 2) * m + j];
+    ux[(n - 1) * m + j] = o;
+    ux[m + j] = 1.f;
+    if (j > 0 && j < m - 1) part += (double)o;
+    uy[j] = uy[m + j];
+    uy[(n - 1) * m + j] = uy[(n - 2) * m + j];
+  }
+  const double ssum = block_sum_d(part, sm);  // contains the barrier between x-loop and y-loop
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    float *rx = ux + i * m, *ry = uy + i * m;
+    rx[0] = rx[1];
+    rx[m - 1] = rx[m - 2];
+    ry[0] = ry[1];
+    ry[m - 1] = ry[m - 2];
+    ry[1] = 0.f;
+    ry[m - 1] = 0.f;
+  }
+  __syncthreads();
+  float s = (float)ssum;
+  s /= (float)(m - 2);
+  const float corr = 1.f - s;
+  for (int j = 1 + threadIdx.x; j < m - 1; j += kThreads) ux[(n - 1) * m + j] += corr;
+  __syncthreads();
+}
+
+// ---- multigrid (MG.pde, PoissonMatrix.pde) ----
+struct Lv {
+  int n, m;
+  const float *lx, *ly, *inv;
+  float *r, *x, *d;
+};
+
+__device__ __forceinline__ Lv make_level(const StepParams &P, size_t e, int l) {
+  Lv L;
+  L.n = P.lev[l].n;
+  L.m = P.lev[l].m;
+  L.lx = P.mg_lx + P.lev[l].coef_off;
+  L.ly = P.mg_ly + P.lev[l].coef_off;
+  L.inv = P.mg_inv + P.lev[l].coef_off;
+  if (l == 0) {
+    const size_t eo = e * (size_t)P.Ns;
+    L.r = P.r + eo;
+    L.x = P.p + eo;
+    L.d = P.d + eo;
+  } else {
+    const int q = P.Cs / 4;
+    float *base = P.coarse + e * (size_t)P.Cs + P.lev[l].scratch_off;
+    L.r = base;
+    L.x = base + q;
+    L.d = base + 2 * q;
+  }
+  return L;
+}
+
+// A.times(x) at an interior cell with ghosts of x read through `clamp` (== x after setBC for a
+// btype-0 field): PoissonMatrix.pde:53-64
+__device__ __forceinline__ float apply_A_clamped(const Lv &L, const float *__restrict__ x, int i, int j) {
+  const int m = L.m, k = i * m + j;
+  const float lw = L.lx[k], le = L.lx[k + m], ls = L.ly[k], ln = L.ly[k + 1];
+  const float diag = -(lw + le + ls + ln);  // PoissonMatrix.pde:45-48
+  const int iw = (i - 1 < 1) ? 1 : i - 1, ie = (i + 1 > L.n - 2) ? L.n - 2 : i + 1;
+  const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m - 2) ? m - 2 : j + 1;
+  return x[k] * diag + x[iw * m + j] * lw + x[ie * m + j] * le + x[i * m + js] * ls + x[i * m + jn] * ln;
+}
+
+// d = r.times(A.inv) on the whole array (MG.pde:80)
+__device__ inline void mg_dinv(const Lv &L) {
+  const int N = L.n * L.m;
+  for (int k = threadIdx.x; k < N; k += kThreads) L.d[k] = L.r[k] * L.inv[k];
+  __syncthreads();
+}
+
+// itmx in-place lexicographic Gauss-Seidel sweeps (MG.pde:81-89), executed in the reference's
+// dependency order as pipelined hyperplanes: cell (i,j) of sweep k runs at step (i-1)+(j-1)+2k,
+// when d[i-1][j], d[i][j-1] already hold sweep-k values and d[i+1][j], d[i][j+1] still hold
+// sweep-(k-1) values -- exactly what the sequential loops see.  Bit-identical to the reference.
+__device__ inline void mg_gs(const Lv &L, int itmx) {
+  const int n_ = L.n - 2, m_ = L.m - 2, m = L.m;
+  const int H = n_ + m_ - 1;
+  const int W = (n_ < m_) ? n_ : m_;
+  const int steps = H + 2 * (itmx - 1);
+  float *d = L.d;
+  for (int tau = 0; tau < steps; ++tau) {
+    for (int w = threadIdx.x; w < itmx * W; w += kThreads) {
+      const int kk = w / W, q = w - kk * W;
+      const int h = tau - 2 * kk;
+      if (h < 0 || h >= H) continue;
+      const int lo = (h - (m_ - 1) > 0) ? h - (m_ - 1) : 0;
+      const int hi = (h < n_ - 1) ? h : n_ - 1;
+      const int ii = lo + q;
+      if (ii > hi) continue;
+      const int i = ii + 1, j = h - ii + 1;
+      const int k = i * m + j;
+      d[k] = -(d[k - m] * L.lx[k] + d[k + m] * L.lx[k + m] + d[k - 1] * L.ly[k] + d[k + 1] * L.ly[k + 1] - L.r[k]) *
+             L.inv[k];
+    }
+    __syncthreads();
+  }
+}
+
+// d.setBC(); increment(): x += d (whole array), r -= A d (interior)   (MG.pde:90-97)
+__device__ inline void mg_increment(const Lv &L) {
+  const int n = L.n, m = L.m, N = n * m;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    const int ci = clampi(i, 1, n - 2), cj = clampi(j, 1, m - 2);
+    L.x[k] += L.d[ci * m + cj];
+    if (ci == i && cj == j) L.r[k] -= apply_A_clamped(L, L.d, i, j);
+  }
+  __syncthreads();
+}
+
+// restrict(r) + setBC, x_coarse = 0  (MG.pde:124-137, 53-59)
+__device__ inline void mg_restrict(const Lv &F, const Lv &Cc) {
+  const int n = Cc.n, m = Cc.m, N = n * m, mf = F.m;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    const int ci = clampi(i, 1, n - 2), cj = clampi(j, 1, m - 2);
+    const int ii = (ci - 1) * 2 + 1, jj = (cj - 1) * 2 + 1;
+    const float *a = F.r + ii * mf + jj;
+    Cc.r[k] = a[0] + a[1] + a[mf] + a[mf + 1];
+    Cc.x[k] = 0.f;
+  }
+  __syncthreads();
+}
+
+// d = prolongate(coarse.x) (+setBC)  (MG.pde:139-152)
+__device__ inline void mg_prolong(const Lv &F, const Lv &Cc) {
+  const int n = F.n, m = F.m, N = n * m, mc = Cc.m;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    const int ci = clampi(i, 1, n - 2), cj = clampi(j, 1, m - 2);
+    F.d[k] = Cc.x[((ci - 1) / 2 + 1) * mc + ((cj - 1) / 2 + 1)];
+  }
+  __syncthreads();
+}
+
+// MGsolver(20, PoissonMatrix(c), p, div u)  (MG.pde:30-38) -- r must hold b - A x on entry
+__device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float *linf_out) {
+  const int kc = P.nlev - 1;
+  int iter = 0;
+  const Lv L0 = make_level(P, e, 0);
+  while (iter < P.mg_max_iters) {
+    ++iter;  // MG.update(), MG.pde:61-66: vCycle(); smooth(its)
+    for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
+      const Lv F = make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      mg_dinv(F);  // smooth(0)
+      mg_increment(F);
+      mg_restrict(F, Cc);
+    }
+    {
+      const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
+      mg_dinv(Lk);
+      mg_gs(Lk, 4);
+      mg_increment(Lk);
+    }
+    for (int l = kc - 1; l >= 0; --l) {  // ascending leg (MG.pde:75-76) + the caller's smooth(its)
+      const Lv F = make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      mg_prolong(F, Cc);
+      mg_increment(F);
+      mg_dinv(F);
+      mg_gs(F, 4);
+      mg_increment(F);
+    }
+    double part = 0;  // r.inner(r): float products, double accumulation (Field.pde:302-310)
+    const int n = L0.n, m = L0.m;
+    for (int k = threadIdx.x; k < n * m; k += kThreads) {
+      const int i = k / m, j = k - i * m;
+      if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+        const float pr = L0.r[k] * L0.r[k];
+        part += (double)pr;
+      }
+    }
+    const float rr = (float)block_sum_d(part, sm);
+    if (rr < P.mg_tol) break;
+  }
+  float mx = 0;  // solver.r.L_inf(), MG.pde:36
+  for (int k = threadIdx.x; k < L0.n * L0.m; k += kThreads) mx = jmax(mx, jabs(L0.r[k]));
+  *linf_out = block_max_f(mx, sm);
+  return iter;
+}
+
+// Phase D+E.  u.project(c, p)  (VectorField.pde:130-143)
+__device__ inline int phase_project(const StepParams &P, size_t e, double *sm, float *linf_out) {
+  const int n = P.n, m = P.m;
+  const size_t eo = e * (size_t)P.Ns;
+  float *ux = P.ux + eo, *uy = P.uy + eo, *p = P.p + eo, *r = P.r + eo;
+  const Lv L0 = make_level(P, e, 0);
+  // r = b - A x with b = divergence (VectorField.pde:56-65, MG.pde:51)
+  for (int k = threadIdx.x; k < P.N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    float rv = 0.f;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float div = ux[k + m] - ux[k] + uy[k + 1] - uy[k];
+      const float lw = L0.lx[k], le = L0.lx[k + m], ls = L0.ly[k], ln = L0.ly[k + 1];
+      const float diag = -(lw + le + ls + ln);
+      const float ap = p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln;
+      rv = div - ap;
+    }
+    r[k] = rv;
+  }
+  __syncthreads();
+  const int iters = mg_solve(P, e, sm, linf_out);
+  // p.plusEq(-1*p.sum()/(float)((n-2)*(m-2)))  (VectorField.pde:136)
+  double part = 0;
+  for (int k = threadIdx.x; k < P.N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) part += (double)p[k];
+  }
+  const float psum = (float)block_sum_d(part, sm);
+  const float shift = -1 * psum / (float)((n - 2) * (m - 2));
+  for (int k = threadIdx.x; k < P.N; k += kThreads) p[k] += shift;
+  __syncthreads();
+  // u -= c * grad p on the cells that survive the following setBC (VectorField.pde:137-139,
+  // Field.pde:71-81)
+  for (int k = threadIdx.x; k < P.N; k += kThreads) {
+    const int i = k / m, j = k - i * m;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float pc = p[k];
+      const float gx = pc - p[k - m], gy = pc - p[k - 1];
+      ux[k] = ux[k] + P.cx[k] * (gx * -1.f);
+      uy[k] = uy[k] + P.cy[k] * (gy * -1.f);
+    }
+  }
+  __syncthreads();
+  phase_setbc_u(P, eo, sm);
+  return iters;
+}
+
+// Body.pressForce(flow.p).mult(-1) of the main cylinder (Body.pde:296-303, AFCCylinder.pde:58)
+__device__ inline void eval_force(const StepParams &P, const float *p, float *fxo, float *fyo) {
+  float px = 0, py = 0;
+  const int m = P.m;
+  for (int s = 0; s < P.nseg; ++s) {
+    const SampleDev sd = P.fs[s];
+    const float *a = p + sd.base;
+    float val;
+    if (sd.exact) {
+      val = a[0];
+    } else {
+      val = sd.s * (sd.t * a[m + 1] + (1 - sd.t) * a[m]) + (1 - sd.s) * (sd.t * a[1] + (1 - sd.t) * a[0]);
+    }
+    const float pdl = val * P.seg_l[s];
+    px += pdl * P.seg_nx[s];
+    py += pdl * P.seg_ny[s];
+  }
+  *fxo = px * -1.f;
+  *fyo = py * -1.f;
+}
+
+struct ShBcast {
+  float fx, fy;
+  int it0, it1;
+  float r0, r1;
+};
+
+// AFCCylinder.update2()  (AFCCylinder.pde:45-61) for env e
+__device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, float xi2_m, double *sm,
+                                ShBcast *sh) {
+  const size_t eo = e * (size_t)P.Ns;
+  const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
+  const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
+  float l0, l1;
+  // flow.update(body): BDIM.pde:126-129, 79-87
+  phase_advdif(P, eo, false);
+  phase_forcing(P, eo, dphi1, dphi2);
+  phase_setbc_u(P, eo, sm);
+  const int it0 = phase_project(P, e, sm, &l0);
+  // flow.update2(body): BDIM.pde:89-107
+  phase_advdif(P, eo, true);
+  phase_forcing(P, eo, dphi1, dphi2);
+  phase_setbc_u(P, eo, sm);
+  const int it1 = phase_project(P, e, sm, &l1);
+  {  // u = (u + us) * 0.5 on the whole array, no setBC (BDIM.pde:95-96)
+    float *ux = P.ux + eo, *uy = P.uy + eo;
+    const float *usx = P.usx + eo, *usy = P.usy + eo;
+    for (int k = threadIdx.x; k < P.N; k += kThreads) {
+      ux[k] = (ux[k] + usx[k]) * 0.5f;
+      uy[k] = (uy[k] + usy[k]) * 0.5f;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float fx, fy;
+    eval_force(P, P.p + eo, &fx, &fy);
+    sh->fx = fx;
+    sh->fy = fy;
+    sh->it0 = it0;
+    sh->it1 = it1;
+    sh->r0 = l0;
+    sh->r1 = l1;
+  }
+  __syncthreads();
+}
+
+}  // namespace afc
