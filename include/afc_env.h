@@ -88,7 +88,10 @@ typedef struct afc_config {
   int32_t mg_max_iters; /* VectorField.pde:135  MGsolver(20, ...) */
   int32_t carry_quirk;  /* 1: keep the Cd/Cl carry of clientCFD.pde:41-47 (reference behaviour) */
   float reward_penalty; /* server.py:64  0.186756 */
-  int32_t reserved[7];
+  int32_t exact_sums;   /* 1: parity mode -- Field.sum (VectorField.pde:136) and Field.inner (MG.pde:34)
+                           are accumulated by one thread in the reference's sequential order, making the
+                           whole step bit-identical to the reference arithmetic; 0 (default): tree sums */
+  int32_t reserved[6];
 } afc_config;
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */

@@ -357,6 +357,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.reward_penalty = cfg->reward_penalty;
   P.substeps = cfg->substeps;
   P.carry_quirk = cfg->carry_quirk;
+  P.exact_sums = cfg->exact_sums;
 
   int rc = AFC_OK;
 #define UP(field) if (!rc) rc = dev_upload(env, &P.field, sf.field)

@@ -8,8 +8,9 @@
 // phases of the other envs resident on the same CU.
 //
 // Arithmetic: float32, -ffp-contract=off, the reference's evaluation order (file:line cited at
-// each function).  The only deviations from the reference's bits are the three order-sensitive
-// reductions (Field.sum, the setBC outflow mean, Field.inner), which are tree reductions here.
+// each function).  The only deviations from the reference's bits are two order-sensitive
+// reductions (Field.sum for the mean pressure, Field.inner for the stopping test), which are tree
+// reductions by default and sequential (bit-identical step) when cfg.exact_sums is set.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,7 +69,7 @@ struct StepParams {
   EnvScalars *sc;
   // episode constants
   float act_scale, init_time, end_time, reward_penalty;
-  int substeps, carry_quirk;
+  int substeps, carry_quirk, exact_sums;
 };
 
 // ---- PApplet float helpers (same semantics as Java's) ----
@@ -234,21 +235,36 @@ __device__ inline void phase_forcing(const StepParams &P, size_t eo, float dphi1
 
 // Phase C.  u.setBC() (Field.pde:209-234): u.x is btype 1 with gradientExit (bval 1),
 // u.y is btype 2 (bval 0).  Statement order of the reference is preserved: x-loop, y-loop,
-// then the outflow-mean correction.  The mean is a tree sum (reference: sequential float).
+// then the outflow-mean correction.  The outflow sum is accumulated by ONE thread in the
+// reference's sequential float order (m-2 <= 1022 values staged in LDS): a tree sum differs in
+// the last bits, and because the Neumann pressure problem is singular that flux rounding
+// shows up as a 1e-4 low-mode drift of p within a few steps.
+constexpr int kRowCap = 1024;
 __device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
+  __shared__ float rowbuf[kRowCap];
+  __shared__ float s_mean;
   const int n = P.n, m = P.m;
   float *ux = P.ux + eo, *uy = P.uy + eo;
-  double part = 0;
   for (int j = threadIdx.x; j < m; j += kThreads) {
     ux[j] = ux[m + j];
     const float o = ux[(n - 2) * m + j];
     ux[(n - 1) * m + j] = o;
     ux[m + j] = 1.f;
-    if (j > 0 && j < m - 1) part += (double)o;
+    if (j < kRowCap) rowbuf[j] = o;
     uy[j] = uy[m + j];
     uy[(n - 1) * m + j] = uy[(n - 2) * m + j];
   }
-  const double ssum = block_sum_d(part, sm);  // contains the barrier between x-loop and y-loop
+  __syncthreads();  // also orders the x-loop before the y-loop
+  if (threadIdx.x == 0) {
+    float s = 0;
+    if (m <= kRowCap) {
+      for (int j = 1; j < m - 1; ++j) s += rowbuf[j];
+    } else {
+      for (int j = 1; j < m - 1; ++j) s += ux[(n - 2) * m + j];
+    }
+    s /= (float)(m - 2);
+    s_mean = s;
+  }
   for (int i = threadIdx.x; i < n; i += kThreads) {
     float *rx = ux + i * m, *ry = uy + i * m;
     rx[0] = rx[1];
@@ -259,11 +275,10 @@ __device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm)
     ry[m - 1] = 0.f;
   }
   __syncthreads();
-  float s = (float)ssum;
-  s /= (float)(m - 2);
-  const float corr = 1.f - s;
+  const float corr = 1.f - s_mean;
   for (int j = 1 + threadIdx.x; j < m - 1; j += kThreads) ux[(n - 1) * m + j] += corr;
   __syncthreads();
+  (void)sm;
 }
 
 // ---- multigrid (MG.pde, PoissonMatrix.pde) ----
@@ -378,6 +393,35 @@ __device__ inline void mg_prolong(const Lv &F, const Lv &Cc) {
   __syncthreads();
 }
 
+// parity mode: the reference's sequential accumulations (Field.pde:302-318), one thread
+__device__ inline float seq_inner(const Lv &L, double *sm) {
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 1; i < L.n - 1; ++i)
+      for (int j = 1; j < L.m - 1; ++j) {
+        const float pr = L.r[i * L.m + j] * L.r[i * L.m + j];
+        s += pr;
+      }
+    reinterpret_cast<float *>(sm)[0] = (float)s;
+  }
+  __syncthreads();
+  const float v = reinterpret_cast<float *>(sm)[0];
+  __syncthreads();
+  return v;
+}
+__device__ inline float seq_sum(const float *a, int n, int m, double *sm) {
+  if (threadIdx.x == 0) {
+    float s = 0;
+    for (int i = 1; i < n - 1; ++i)
+      for (int j = 1; j < m - 1; ++j) s += a[i * m + j];
+    reinterpret_cast<float *>(sm)[0] = s;
+  }
+  __syncthreads();
+  const float v = reinterpret_cast<float *>(sm)[0];
+  __syncthreads();
+  return v;
+}
+
 // MGsolver(20, PoissonMatrix(c), p, div u)  (MG.pde:30-38) -- r must hold b - A x on entry
 __device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float *linf_out) {
   const int kc = P.nlev - 1;
@@ -414,7 +458,8 @@ __device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float 
         part += (double)pr;
       }
     }
-    const float rr = (float)block_sum_d(part, sm);
+    float rr = (float)block_sum_d(part, sm);
+    if (P.exact_sums) rr = seq_inner(L0, sm);
     if (rr < P.mg_tol) break;
   }
   float mx = 0;  // solver.r.L_inf(), MG.pde:36
@@ -450,7 +495,8 @@ __device__ inline int phase_project(const StepParams &P, size_t e, double *sm, f
     const int i = k / m, j = k - i * m;
     if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) part += (double)p[k];
   }
-  const float psum = (float)block_sum_d(part, sm);
+  float psum = (float)block_sum_d(part, sm);
+  if (P.exact_sums) psum = seq_sum(p, n, m, sm);
   const float shift = -1 * psum / (float)((n - 2) * (m - 2));
   for (int k = threadIdx.x; k < P.N; k += kThreads) p[k] += shift;
   __syncthreads();
