@@ -91,7 +91,9 @@ typedef struct afc_config {
   int32_t exact_sums;   /* 1: parity mode -- Field.sum (VectorField.pde:136) and Field.inner (MG.pde:34)
                            are accumulated by one thread in the reference's sequential order, making the
                            whole step bit-identical to the reference arithmetic; 0 (default): tree sums */
-  int32_t reserved[6];
+  int32_t impl;         /* 2 (default): optimised kernels; 0: the straightforward reference kernels
+                           (same arithmetic; kept for A/B timing and bisecting) */
+  int32_t reserved[5];
 } afc_config;
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */
@@ -157,6 +159,10 @@ int afc_get_probes(afc_env *env, int num, float *out);
  * and returns the coarse arrays [n_l*m_l] */
 int afc_get_static(afc_env *env, int which, int level, float *out);
 int afc_level_dims(const afc_env *env, int level, int32_t *n, int32_t *m);
+
+/* diagnostics: per-phase wall-clock ticks (100 MHz) accumulated by env 0 since the last call;
+ * enable!=0 turns accumulation on.  Phase ids: see afc::PF_* in csrc/bdim_device.h. */
+int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count);
 
 /* --- unit-level device entry points (parity tests drive single operators through the same
  * kernels the step uses; all pointers HOST, reference layout) --- */

@@ -14,7 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libafc_env.so")
 SOURCES = ["afc_env.hip", "geometry.cpp"]
-DEPS = SOURCES + ["bdim_device.h", "geometry.h", os.path.join("..", "..", "include", "afc_env.h")]
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
+    d.append(os.path.join(HERE, "..", "include", "afc_env.h"))
+    return d
+
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -23,7 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=False):

@@ -13,6 +13,7 @@
 
 #include "../../include/afc_env.h"
 #include "bdim_device.h"
+#include "bdim_v2.h"
 #include "geometry.h"
 
 namespace {
@@ -34,13 +35,27 @@ using afc::kThreads;
 using afc::StepParams;
 
 // ---------------- kernels ----------------
-__global__ __launch_bounds__(afc::kThreads) void k_sim_step(StepParams P, const float *__restrict__ xi_m,
-                                                            float *__restrict__ force) {
+// CPL = columns per lane of the optimised kernels (grid height m-2 <= 64*CPL); CPL = 0 selects the
+// straightforward reference kernels.  One instantiation per CPL keeps each kernel's register
+// budget at 4 workgroups (16 waves) per CU.
+template <int CPL>
+__device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, double *sm,
+                                              afc::ShBcast *sh, float *lds) {
+  if constexpr (CPL == 0)
+    afc::sim_step(P, e, a, b, sm, sh);
+  else
+    afc::sim_step_v2<CPL>(P, e, a, b, sm, sh, lds);
+}
+
+template <int CPL>
+__global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(StepParams P, const float *__restrict__ xi_m,
+                                                               float *__restrict__ force) {
   __shared__ double sm[afc::kThreads];
   __shared__ afc::ShBcast sh;
+  extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
-  afc::sim_step(P, e, a, b, sm, &sh);
+  step_dispatch<CPL>(P, e, a, b, sm, &sh, lds_dyn);
   if (threadIdx.x == 0) {
     EnvScalars &s = P.sc[e];
     s.xi1_m = a;
@@ -62,12 +77,14 @@ __global__ __launch_bounds__(afc::kThreads) void k_sim_step(StepParams P, const 
 }
 
 // The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
-__global__ __launch_bounds__(afc::kThreads) void k_agent_step(StepParams P, const float *__restrict__ action,
-                                                              float *__restrict__ obs, float *__restrict__ reward,
-                                                              uint8_t *__restrict__ done, int *__restrict__ nsteps,
-                                                              int max_steps) {
+template <int CPL>
+__global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(StepParams P, const float *__restrict__ action,
+                                                                 float *__restrict__ obs, float *__restrict__ reward,
+                                                                 uint8_t *__restrict__ done, int *__restrict__ nsteps,
+                                                                 int max_steps) {
   __shared__ double sm[afc::kThreads];
   __shared__ afc::ShBcast sh;
+  extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
   EnvScalars s = P.sc[e];  // every thread keeps an identical private copy (uniform control flow)
   const float a1 = action[2 * e], a2 = action[2 * e + 1];
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(afc::kThreads) void k_agent_step(StepParams P, cons
   bool got = false;
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
-    afc::sim_step(P, e, s.xi1_m, s.xi2_m, sm, &sh);
+    step_dispatch<CPL>(P, e, s.xi1_m, s.xi2_m, sm, &sh, lds_dyn);
     ++steps;
     s.t += P.dt / P.resolution;
     s.force_x = sh.fx;
@@ -179,7 +196,21 @@ __global__ void k_probes(StepParams P, const afc::SampleDev *__restrict__ ps, in
 
 // unit-level operators on env 0 (same device functions as the step)
 __global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
-  afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
+  extern __shared__ float lds_dyn[];
+  if (P.impl == 0) {
+    afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
+    return;
+  }
+  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {  // F starts as a copy of u (VectorField.pde:171)
+    P.fx[k] = P.ux[k];
+    P.fy[k] = P.uy[k];
+  }
+  __syncthreads();
+  const int m_ = P.m - 2;
+  if (m_ <= 64) afc::advdif_v2<1>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
+  else if (m_ <= 128) afc::advdif_v2<2>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
+  else if (m_ <= 192) afc::advdif_v2<3>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
+  else afc::advdif_v2<4>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
 }
 __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   __shared__ double sm[afc::kThreads];
@@ -203,7 +234,10 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iter
   }
   __syncthreads();
   float l;
-  const int it = afc::mg_solve(P, 0, sm, &l);
+  afc::Prof pf;
+  pf.start(P);
+  extern __shared__ float lds_dyn[];
+  const int it = afc::mg_solve(P, 0, sm, &l, pf, P.impl ? lds_dyn : nullptr);
   if (threadIdx.x == 0) {
     *iters = it;
     *linf = l;
@@ -228,6 +262,9 @@ struct afc_env {
   float *d_in = nullptr, *d_f2 = nullptr, *d_f1 = nullptr;
   uint8_t *d_u8 = nullptr;
   int32_t *d_i32 = nullptr;
+  long long *d_stamps = nullptr;
+  size_t lds_bytes = 0;
+  int cpl = 0;  // kernel instantiation: columns per lane (0 = reference kernels)
   std::vector<int> level_off;
   afc::SampleDev *d_probes = nullptr;
   int n_probes = 0;
@@ -298,6 +335,8 @@ int afc_default_config(afc_config *cfg) {
   cfg->device = 0;
   cfg->mg_max_iters = 20;
   cfg->carry_quirk = 0;
+  cfg->exact_sums = 0;
+  cfg->impl = 2;
   cfg->reward_penalty = (float)(3.14159265358979323846 * (1.0 / 8) * 0.0097 * (3.66 * 3.66 * 3.66));
   return AFC_OK;
 }
@@ -307,6 +346,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   *out = nullptr;
   if (cfg->num_envs < 1) return fail(AFC_EINVAL, "afc_create: num_envs must be >= 1");
   if (cfg->substeps < 1 || cfg->mg_max_iters < 1) return fail(AFC_EINVAL, "afc_create: substeps/mg_max_iters");
+  if (cfg->impl != 0 && cfg->impl != 2) return fail(AFC_EINVAL, "afc_create: impl must be 0 (reference kernels) or 2");
+  if (cfg->y_lengths * cfg->resolution > 256 && cfg->impl != 0) return fail(AFC_EINVAL, "afc_create: impl 2 supports up to 256 cells in y");
   int ndev = 0;
   hipError_t he = hipGetDeviceCount(&ndev);
   if (he != hipSuccess || ndev < 1)
@@ -358,12 +399,23 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.substeps = cfg->substeps;
   P.carry_quirk = cfg->carry_quirk;
   P.exact_sums = cfg->exact_sums;
+  P.impl = cfg->impl;
+  P.adv_rows = (sf.m <= 130) ? 16 : 8;
+  env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
+  {
+    const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 2;  // advdif_v2
+    const size_t rings = 32 + (size_t)(2 * afc::kRing + 4) * sf.m + 32 + 64;  // mg_up_smooth (gs_lds_floats)
+    env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * (tile > rings ? tile : rings);
+  }
 
   int rc = AFC_OK;
 #define UP(field) if (!rc) rc = dev_upload(env, &P.field, sf.field)
   UP(delx); UP(dely); UP(del1x); UP(del1y); UP(wnxx); UP(wnxy); UP(wnyx); UP(wnyy); UP(cx); UP(cy);
   UP(w1x); UP(w2x); UP(ry1x); UP(ry2x); UP(w1y); UP(w2y); UP(rx1y); UP(rx2y);
   UP(seg_l); UP(seg_nx); UP(seg_ny);
+  UP(band_x); UP(band_y);
+  P.nband_x = (int)sf.band_x.size();
+  P.nband_y = (int)sf.band_y.size();
 #undef UP
   // multigrid hierarchy, all levels concatenated
   std::vector<float> lx, ly, inv;
@@ -374,6 +426,32 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     P.lev[l].m = L.m;
     P.lev[l].coef_off = coff;
     P.lev[l].scratch_off = (l == 0) ? 0 : soff;
+    {  // analytic coefficient model of the level + rows where the real arrays deviate from it
+      afc::LevelDesc &D = P.lev[l];
+      D.cu = sf.dt;
+      D.zero_bnd = (l > 0) ? 1 : 0;
+      for (int rc = 0; rc < 3; ++rc)
+        for (int cc = 0; cc < 3; ++cc) {
+          const float lw = (rc == 1 && D.zero_bnd) ? 0.f : D.cu, le = (rc == 2 && D.zero_bnd) ? 0.f : D.cu;
+          const float ls = (cc == 1 && D.zero_bnd) ? 0.f : D.cu, ln = (cc == 2 && D.zero_bnd) ? 0.f : D.cu;
+          const float sumd = lw + le + ls + ln;
+          D.invtab[3 * rc + cc] = (sumd > 1e-5f) ? -1.f / sumd : 1.f;
+        }
+      D.sp_i0 = 1 << 30;
+      D.sp_i1 = -1;
+      for (int i = 1; i < L.n - 1; ++i)
+        for (int j = 1; j < L.m - 1; ++j) {
+          const size_t k = (size_t)i * L.m + j;
+          const int rc = (i == 1) ? 1 : ((i == L.n - 2) ? 2 : 0), cc = (j == 1) ? 1 : ((j == L.m - 2) ? 2 : 0);
+          const float lw = (rc == 1 && D.zero_bnd) ? 0.f : D.cu, le = (rc == 2 && D.zero_bnd) ? 0.f : D.cu;
+          const float ls = (cc == 1 && D.zero_bnd) ? 0.f : D.cu, ln = (cc == 2 && D.zero_bnd) ? 0.f : D.cu;
+          if (L.lx[k] != lw || L.lx[k + L.m] != le || L.ly[k] != ls || L.ly[k + 1] != ln ||
+              L.inv[k] != D.invtab[3 * rc + cc]) {
+            if (i < D.sp_i0) D.sp_i0 = i;
+            if (i > D.sp_i1) D.sp_i1 = i;
+          }
+        }
+    }
     const int cnt = L.n * L.m;
     lx.insert(lx.end(), L.lx.begin(), L.lx.end());
     ly.insert(ly.end(), L.ly.begin(), L.ly.end());
@@ -386,6 +464,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     if (l >= 1) soff += cnt + pad;
   }
   P.Cs = 4 * ((soff + 63) / 64 * 64);
+  lx.insert(lx.end(), 128, 0.f);  // tail padding: the strip Gauss-Seidel prefetches a few cells past a row
+  ly.insert(ly.end(), 128, 0.f);
+  inv.insert(inv.end(), 128, 1.f);
   if (!rc) rc = dev_upload(env, &P.mg_lx, lx);
   if (!rc) rc = dev_upload(env, &P.mg_ly, ly);
   if (!rc) rc = dev_upload(env, &P.mg_inv, inv);
@@ -412,6 +493,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_alloc(env, &env->d_f1, E);
   if (!rc) rc = dev_alloc(env, &env->d_u8, E);
   if (!rc) rc = dev_alloc(env, &env->d_i32, E * 2);
+  if (!rc) rc = dev_alloc(env, &env->d_stamps, (size_t)32);
+  if (!rc && hipMemset(env->d_stamps, 0, 32 * sizeof(long long)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (rc) {
     afc_destroy(env);
     return rc;
@@ -430,9 +513,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
 
 int afc_destroy(afc_env *env) {
   if (!env) return AFC_OK;
-  hipSetDevice(env->cfg.device);
-  hipDeviceSynchronize();
-  for (void *p : env->allocs) hipFree(p);
+  (void)hipSetDevice(env->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void *p : env->allocs) (void)hipFree(p);
   delete env;
   return AFC_OK;
 }
@@ -567,7 +650,11 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
     dxi = env->d_in;
     dforce = env->d_f2;
   }
-  hipLaunchKernelGGL(k_sim_step, dim3(env->E), dim3(kThreads), 0, env->stream, env->P, dxi, dforce);
+  switch (env->cpl) {
+#define LAUNCH(c) case c: hipLaunchKernelGGL(k_sim_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, env->P, dxi, dforce); break
+    LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#undef LAUNCH
+  }
   int rc = launch_check("k_sim_step");
   if (rc) return rc;
   if (env->io_space == AFC_MEM_HOST) {
@@ -599,9 +686,13 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   }
   // upper bound on sim-steps per call: warm-up (t <= init_time) + one averaging window
   const float per = env->P.dt / env->cfg.resolution;
-  const int max_steps = (int)(env->cfg.init_time / per) + 2 * env->cfg.substeps + 8;
-  hipLaunchKernelGGL(k_agent_step, dim3(env->E), dim3(kThreads), 0, env->stream, env->P, dact, dobs, drew, ddone,
-                     dns, max_steps);
+  const int warm = (int)(env->cfg.init_time / per);
+  const int max_steps = (warm > 0 ? warm : 0) + 2 * env->cfg.substeps + 8;
+  switch (env->cpl) {
+#define LAUNCH(c) case c: hipLaunchKernelGGL(k_agent_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, env->P, dact, dobs, drew, ddone, dns, max_steps); break
+    LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#undef LAUNCH
+  }
   int rc = launch_check("k_agent_step");
   if (rc) return rc;
   if (host) {
@@ -724,7 +815,7 @@ int afc_get_probes(afc_env *env, int num, float *out) {
     if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)env->E * num * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(AFC_EHIP, hipGetErrorString(e));
   }
-  hipFree(dout);
+  (void)hipFree(dout);
   return rc;
 }
 
@@ -761,6 +852,19 @@ int afc_get_static(afc_env *env, int which, int level, float *out) {
   return AFC_OK;
 }
 
+int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count) {
+  if (check_env(env)) return AFC_EINVAL;
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  if (ticks_out && count > 0) {
+    if (count > 32) count = 32;
+    HIP_TRY(hipMemcpy(ticks_out, env->d_stamps, count * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  HIP_TRY(hipMemset(env->d_stamps, 0, 32 * sizeof(long long)));
+  env->P.stamps = enable ? env->d_stamps : nullptr;
+  return AFC_OK;
+}
+
 // ---- unit-level operators (env 0's buffers are used as scratch: state of env 0 is clobbered) ----
 int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const float *u0y) {
   if (check_env(env)) return AFC_EINVAL;
@@ -773,7 +877,7 @@ int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const fl
   HIP_TRY(hipMemcpy(P.uy, fy, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(P.u0x, u0x, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(P.u0y, u0y, bytes, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_op_advdif, dim3(1), dim3(kThreads), 0, env->stream, P);
+  hipLaunchKernelGGL(k_op_advdif, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
   int rc = launch_check("k_op_advdif");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
@@ -811,7 +915,7 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   HIP_TRY(hipMemcpy(P.fx, b, bytes, hipMemcpyHostToDevice));
   int *dit = reinterpret_cast<int *>(env->d_i32);
   float *dl = env->d_f1;
-  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), 0, env->stream, P, dit, dl);
+  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));

@@ -24,6 +24,14 @@ struct LevelDesc {
   int n, m;          // array size incl. ghosts
   int coef_off;      // offset (floats) of this level in mg_lx/mg_ly/mg_inv
   int scratch_off;   // offset (floats) of this level in the per-env coarse scratch (levels >= 1)
+  // analytic description of the coefficients away from the bodies (verified on the host against
+  // the real arrays): every face coefficient equals `cu`, except the four boundary face lines
+  // which are 0 when zero_bnd (coarse levels, MG.pde:120); inv = invtab[3*rowclass+colclass]
+  // (class 0 interior, 1 first, 2 last).  Rows [sp_i0, sp_i1] contain cells that deviate.
+  float cu;
+  int zero_bnd;
+  float invtab[9];
+  int sp_i0, sp_i1;
 };
 
 struct SampleDev {
@@ -67,9 +75,15 @@ struct StepParams {
   float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d;
   float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
   EnvScalars *sc;
+  long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
   // episode constants
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
+  // v2 path
+  int impl;            // 0 = v1 reference kernels, 2 = optimised kernels
+  int adv_rows;        // rows per LDS tile block in advdif_v2
+  const int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
+  int nband_x, nband_y;
 };
 
 // ---- PApplet float helpers (same semantics as Java's) ----
@@ -80,6 +94,25 @@ __device__ __forceinline__ float med3(float a, float b, float c) {  // VectorFie
   return jmax(jmin(a, b), jmin(jmax(a, b), c));
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- optional phase profiling (env 0, thread 0; ticks of wall_clock64 = 100 MHz) ----
+struct Prof {
+  long long *acc;
+  long long last;
+  __device__ void start(const StepParams &P) {
+    acc = (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? P.stamps : nullptr;
+    if (acc) last = wall_clock64();
+  }
+  __device__ __forceinline__ void mark(int id) {
+    if (acc) {
+      const long long now = wall_clock64();
+      acc[id] += now - last;
+      last = now;
+    }
+  }
+};
+enum { PF_ADVDIF = 0, PF_FORCING, PF_SETBC, PF_RESID, PF_DOWN0, PF_COARSE_DOWN, PF_COARSE_GS, PF_COARSE_UP, PF_UP0,
+       PF_GS0, PF_INC0, PF_RR, PF_PROJECT, PF_HEUN, PF_COUNT };
 
 // ---- workgroup reductions (fixed tree order => deterministic) ----
 __device__ inline double block_sum_d(double v, double *sm) {
@@ -240,11 +273,10 @@ __device__ inline void phase_forcing(const StepParams &P, size_t eo, float dphi1
 // the last bits, and because the Neumann pressure problem is singular that flux rounding
 // shows up as a 1e-4 low-mode drift of p within a few steps.
 constexpr int kRowCap = 1024;
-__device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
+__device__ inline void setbc_vel(const StepParams &P, float *ux, float *uy) {
   __shared__ float rowbuf[kRowCap];
   __shared__ float s_mean;
   const int n = P.n, m = P.m;
-  float *ux = P.ux + eo, *uy = P.uy + eo;
   for (int j = threadIdx.x; j < m; j += kThreads) {
     ux[j] = ux[m + j];
     const float o = ux[(n - 2) * m + j];
@@ -278,7 +310,10 @@ __device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm)
   const float corr = 1.f - s_mean;
   for (int j = 1 + threadIdx.x; j < m - 1; j += kThreads) ux[(n - 1) * m + j] += corr;
   __syncthreads();
+}
+__device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
   (void)sm;
+  setbc_vel(P, P.ux + eo, P.uy + eo);
 }
 
 // ---- multigrid (MG.pde, PoissonMatrix.pde) ----
@@ -286,6 +321,7 @@ struct Lv {
   int n, m;
   const float *lx, *ly, *inv;
   float *r, *x, *d;
+  const LevelDesc *desc;
 };
 
 __device__ __forceinline__ Lv make_level(const StepParams &P, size_t e, int l) {
@@ -295,6 +331,7 @@ __device__ __forceinline__ Lv make_level(const StepParams &P, size_t e, int l) {
   L.lx = P.mg_lx + P.lev[l].coef_off;
   L.ly = P.mg_ly + P.lev[l].coef_off;
   L.inv = P.mg_inv + P.lev[l].coef_off;
+  L.desc = &P.lev[l];
   if (l == 0) {
     const size_t eo = e * (size_t)P.Ns;
     L.r = P.r + eo;
@@ -423,7 +460,17 @@ __device__ inline float seq_sum(const float *a, int n, int m, double *sm) {
 }
 
 // MGsolver(20, PoissonMatrix(c), p, div u)  (MG.pde:30-38) -- r must hold b - A x on entry
-__device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float *linf_out) {
+__device__ inline int mg_solve_v2(const StepParams &P, size_t e, double *sm, float *linf_out, Prof &pf, float *lds);
+__device__ inline void mg_smooth4(const StepParams &P, const Lv &L, float *lds) {
+  (void)P;
+  (void)lds;
+  mg_dinv(L);
+  mg_gs(L, 4);
+}
+
+__device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float *linf_out, Prof &pf,
+                               float *lds = nullptr) {
+  if (P.impl != 0 && lds != nullptr) return mg_solve_v2(P, e, sm, linf_out, pf, lds);
   const int kc = P.nlev - 1;
   int iter = 0;
   const Lv L0 = make_level(P, e, 0);
@@ -434,20 +481,23 @@ __device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float 
       mg_dinv(F);  // smooth(0)
       mg_increment(F);
       mg_restrict(F, Cc);
+      pf.mark(l == 0 ? PF_DOWN0 : PF_COARSE_DOWN);
     }
     {
       const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
-      mg_dinv(Lk);
-      mg_gs(Lk, 4);
+      mg_smooth4(P, Lk, lds);
       mg_increment(Lk);
+      pf.mark(PF_COARSE_GS);
     }
     for (int l = kc - 1; l >= 0; --l) {  // ascending leg (MG.pde:75-76) + the caller's smooth(its)
       const Lv F = make_level(P, e, l), Cc = make_level(P, e, l + 1);
       mg_prolong(F, Cc);
       mg_increment(F);
-      mg_dinv(F);
-      mg_gs(F, 4);
+      pf.mark(l == 0 ? PF_UP0 : PF_COARSE_UP);
+      mg_smooth4(P, F, lds);
+      pf.mark(l == 0 ? PF_GS0 : PF_COARSE_GS);
       mg_increment(F);
+      pf.mark(l == 0 ? PF_INC0 : PF_COARSE_UP);
     }
     double part = 0;  // r.inner(r): float products, double accumulation (Field.pde:302-310)
     const int n = L0.n, m = L0.m;
@@ -460,6 +510,7 @@ __device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float 
     }
     float rr = (float)block_sum_d(part, sm);
     if (P.exact_sums) rr = seq_inner(L0, sm);
+    pf.mark(PF_RR);
     if (rr < P.mg_tol) break;
   }
   float mx = 0;  // solver.r.L_inf(), MG.pde:36
@@ -469,10 +520,11 @@ __device__ inline int mg_solve(const StepParams &P, size_t e, double *sm, float 
 }
 
 // Phase D+E.  u.project(c, p)  (VectorField.pde:130-143)
-__device__ inline int phase_project(const StepParams &P, size_t e, double *sm, float *linf_out) {
+__device__ inline int project_vel(const StepParams &P, size_t e, float *ux, float *uy, double *sm, float *linf_out,
+                                  Prof &pf, float *lds = nullptr) {
   const int n = P.n, m = P.m;
   const size_t eo = e * (size_t)P.Ns;
-  float *ux = P.ux + eo, *uy = P.uy + eo, *p = P.p + eo, *r = P.r + eo;
+  float *p = P.p + eo, *r = P.r + eo;
   const Lv L0 = make_level(P, e, 0);
   // r = b - A x with b = divergence (VectorField.pde:56-65, MG.pde:51)
   for (int k = threadIdx.x; k < P.N; k += kThreads) {
@@ -488,7 +540,8 @@ __device__ inline int phase_project(const StepParams &P, size_t e, double *sm, f
     r[k] = rv;
   }
   __syncthreads();
-  const int iters = mg_solve(P, e, sm, linf_out);
+  pf.mark(PF_RESID);
+  const int iters = mg_solve(P, e, sm, linf_out, pf, lds);
   // p.plusEq(-1*p.sum()/(float)((n-2)*(m-2)))  (VectorField.pde:136)
   double part = 0;
   for (int k = threadIdx.x; k < P.N; k += kThreads) {
@@ -512,8 +565,13 @@ __device__ inline int phase_project(const StepParams &P, size_t e, double *sm, f
     }
   }
   __syncthreads();
-  phase_setbc_u(P, eo, sm);
+  setbc_vel(P, ux, uy);
+  pf.mark(PF_PROJECT);
   return iters;
+}
+__device__ inline int phase_project(const StepParams &P, size_t e, double *sm, float *linf_out, Prof &pf) {
+  const size_t eo = e * (size_t)P.Ns;
+  return project_vel(P, e, P.ux + eo, P.uy + eo, sm, linf_out, pf);
 }
 
 // Body.pressForce(flow.p).mult(-1) of the main cylinder (Body.pde:296-303, AFCCylinder.pde:58)
@@ -550,16 +608,24 @@ __device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, floa
   const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
   const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
   float l0, l1;
+  Prof pf;
+  pf.start(P);
   // flow.update(body): BDIM.pde:126-129, 79-87
   phase_advdif(P, eo, false);
+  pf.mark(PF_ADVDIF);
   phase_forcing(P, eo, dphi1, dphi2);
+  pf.mark(PF_FORCING);
   phase_setbc_u(P, eo, sm);
-  const int it0 = phase_project(P, e, sm, &l0);
+  pf.mark(PF_SETBC);
+  const int it0 = phase_project(P, e, sm, &l0, pf);
   // flow.update2(body): BDIM.pde:89-107
   phase_advdif(P, eo, true);
+  pf.mark(PF_ADVDIF);
   phase_forcing(P, eo, dphi1, dphi2);
+  pf.mark(PF_FORCING);
   phase_setbc_u(P, eo, sm);
-  const int it1 = phase_project(P, e, sm, &l1);
+  pf.mark(PF_SETBC);
+  const int it1 = phase_project(P, e, sm, &l1, pf);
   {  // u = (u + us) * 0.5 on the whole array, no setBC (BDIM.pde:95-96)
     float *ux = P.ux + eo, *uy = P.uy + eo;
     const float *usx = P.usx + eo, *usy = P.usy + eo;
@@ -579,6 +645,7 @@ __device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, floa
     sh->r1 = l1;
   }
   __syncthreads();
+  pf.mark(PF_HEUN);
 }
 
 }  // namespace afc

@@ -260,6 +260,13 @@ StaticFields build_static(const CaseParams &cp) {
   set_bc(sf.del1x, n, m, 1, 0.f);  // BDIM.pde:195
   set_bc(sf.del1y, n, m, 2, 0.f);
 
+  for (int i = 1; i < n - 1; ++i)
+    for (int j = 1; j < m - 1; ++j) {
+      const int k = i * m + j;
+      if (sf.delx[k] != 1.f || sf.del1x[k] != 0.f) sf.band_x.push_back(k);
+      if (sf.dely[k] != 1.f || sf.del1y[k] != 0.f) sf.band_y.push_back(k);
+    }
+
   // c = del * (rhoi*dt), BDIM.pde:81 (rhoi == 1 everywhere, BDIM.pde:61)
   sf.cx.resize(N);
   sf.cy.resize(N);

@@ -47,6 +47,8 @@ struct StaticFields {
   std::vector<float> seg_l, seg_nx, seg_ny;
   // band of cells touched by the immersed-boundary forcing (|d|<eps) -- informational
   int band_cells = 0, ub_cells = 0;
+  // interior cells where BDIM.updateUP is not the identity (del != 1 or del1 != 0), per component
+  std::vector<int> band_x, band_y;
 };
 
 // Builds all of the above.  Throws std::runtime_error on an invalid configuration

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "afc_load_state_bdim", "afc_set_reset_state", "afc_save_state_bdim", "afc_reset", "afc_sim_step",
     "afc_agent_step", "afc_get_time", "afc_get_solver_stats", "afc_get_diverged", "afc_get_field",
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
-    "afc_op_mg_solve", "afc_op_setbc_u",
+    "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases",
 ]
 
 
@@ -36,7 +36,7 @@ class AfcConfig(C.Structure):
         ("theta", C.c_float), ("act_scale", C.c_float), ("substeps", C.c_int32),
         ("init_time", C.c_float), ("end_time", C.c_float), ("num_envs", C.c_int32),
         ("device", C.c_int32), ("mg_max_iters", C.c_int32), ("carry_quirk", C.c_int32),
-        ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("impl", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     L.afc_op_advdif.argtypes = [vp, f32p, f32p, f32p, f32p]
     L.afc_op_mg_solve.argtypes = [vp, f32p, f32p, i32p, C.POINTER(C.c_float)]
     L.afc_op_setbc_u.argtypes = [vp, f32p, f32p]
+    L.afc_profile_phases.argtypes = [vp, C.c_int, vp, C.c_int]
     _lib = L
     return L
 
@@ -261,6 +262,15 @@ class AFCEnv:
     def agent_step_device(self, action_ptr, obs_ptr, reward_ptr, done_ptr, nsteps_ptr=0):
         self._ck(self._L.afc_agent_step(self._h, C.c_void_p(action_ptr), C.c_void_p(obs_ptr), C.c_void_p(reward_ptr),
                                         C.c_void_p(done_ptr), C.c_void_p(nsteps_ptr or 0)), "afc_agent_step")
+
+    PHASES = ["advdif", "forcing", "setbc", "resid", "down0", "coarse_down", "coarse_gs", "coarse_up", "up0",
+              "gs0", "inc0", "rr", "project", "heun"]
+
+    def profile_phases(self, enable=True):
+        """returns {phase: microseconds} accumulated by env 0 since the last call"""
+        out = np.zeros(32, np.int64)
+        self._ck(self._L.afc_profile_phases(self._h, int(enable), _np_ptr(out), 32), "afc_profile_phases")
+        return {k: out[i] / 100.0 for i, k in enumerate(self.PHASES)}
 
     # -- unit-level operators (parity tests) --
     def op_advdif(self, fx, fy, u0x, u0y):

@@ -54,8 +54,9 @@ def test_static_fields_bit_exact(envmod, oracle_mod, res, Re):
     g.close()
 
 
-def test_advdif_bit_exact(envmod, oracle_mod, init_bdim):
-    g = envmod.AFCEnv(num_envs=1, resolution=24, reynolds=500)
+@pytest.mark.parametrize("impl", [0, 2])
+def test_advdif_bit_exact(envmod, oracle_mod, init_bdim, impl):
+    g = envmod.AFCEnv(num_envs=1, resolution=24, reynolds=500, impl=impl)
     L = oracle_mod.lib()
     u, v = init_bdim["u"], init_bdim["v"]
     rng = np.random.default_rng(1)
@@ -83,10 +84,11 @@ def test_setbc_u(envmod, oracle_mod):
     g.close()
 
 
-@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100)])
-def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re):
+@pytest.mark.parametrize("impl", [0, 2])
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100), (24, 500)])
+def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re, impl):
     """MGsolver on the env's own coefficient hierarchy, random divergence-like rhs"""
-    g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re)
+    g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re, impl=impl)
     o = oracle_mod.Oracle(resolution=res, Re=Re)
     o.update2(0.0, 0.0)
     lx, ly = o.coeff("c.x"), o.coeff("c.y")
@@ -107,8 +109,8 @@ def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re):
     g.close()
 
 
-def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0):
-    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact)
+def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0, impl=2):
+    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact, impl=impl)
     o = oracle_mod.Oracle(resolution=res, Re=Re)
     if init is not None:
         g.set_reset_state(init["u"], init["v"], init["p"])
@@ -176,11 +178,13 @@ def test_envs_are_independent(envmod, oracle_mod):
     g.close()
 
 
+@pytest.mark.parametrize("impl", [0, 2])
 @pytest.mark.parametrize("res,Re,init", [(8, 100, False), (16, 100, False), (24, 500, True)])
-def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init):
+def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init, impl):
     """cfg.exact_sums=1: every float the step produces equals the oracle's, bit for bit."""
     acts = [(0, 0)] * 3 + [(5.0, -5.0)] * 5 + [(-2.5, 1.0)] * 4 + [(0, 0)] * 4
-    g, o, out = _run_pair(envmod, oracle_mod, res, Re, len(acts), acts, init=init_bdim if init else None, exact=1)
+    g, o, out = _run_pair(envmod, oracle_mod, res, Re, len(acts), acts, init=init_bdim if init else None, exact=1,
+                          impl=impl)
     for k, (fg, fo, itg, ito) in enumerate(out):
         assert tuple(itg[0]) == tuple(ito), k
         assert np.array_equal(fg[0], fo), (k, fg[0], fo)
