@@ -249,7 +249,10 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
     iv1 = D.invtab[3 * rc + 1];
     iv2 = D.invtab[3 * rc + 2];
   }
-  const float lsB = D.zero_bnd ? 0.f : D.cu, cu = D.cu;
+  const float cu = D.cu;
+  const bool zb = D.zero_bnd != 0;
+  (void)lwU;
+  (void)leU;
   const int steps = (m_ + 18 + 3) & ~3;  // multiple of 4 (the extra steps are inactive)
   // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k); nothing is
   // clamped -- before/after its row a lane reads whatever lies beside it in LDS and discards it.
@@ -269,7 +272,17 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
   const bool wd_lane = row_ok && (k == 3);
   const bool wc_lane = (c == 15);
   float *const dmy = dummy + lane;
-  float n_rv = p_rv[0], n_cW = p_cW[0], n_cN = p_cN[0], n_dE0 = p_dE[0], n_dN0 = p_dN[0];
+  // LDS operands of the four steps of a chunk are fetched one chunk ahead (<= 7 steps early: still
+  // far inside the hazard margins above)
+  float o_rv[4], o_cW[4], o_cN[4], o_dE[4], o_dN[4], y_rv[4], y_cW[4], y_cN[4], y_dE[4], y_dN[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y_rv[e] = p_rv[e];
+    y_cW[e] = p_cW[e];
+    y_cN[e] = p_cN[e];
+    y_dE[e] = p_dE[e];
+    y_dN[e] = p_dN[e];
+  }
   F4 c_lw, c_le, c_ls, c_iv, x_lw, x_le, x_ls, x_iv;
   float c_ln4 = 0.f, x_ln4 = 0.f;
   const int cbase = ic * m + jo;  // + tau = flat index of this lane's cell at step tau
@@ -294,8 +307,24 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       c_ln4 = x_ln4;
       GS_CHUNK(tau0 + 4, x_lw, x_le, x_ls, x_iv, x_ln4)
     }
-    const float *q_rv = p_rv + tau0, *q_cW = p_cW + tau0, *q_cN = p_cN + tau0, *q_dE = p_dE + tau0,
-                *q_dN = p_dN + tau0;
+    const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4,
+                *q_dN = p_dN + tau0 + 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o_rv[e] = y_rv[e];
+      o_cW[e] = y_cW[e];
+      o_cN[e] = y_cN[e];
+      o_dE[e] = y_dE[e];
+      o_dN[e] = y_dN[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y_rv[e] = q_rv[e];
+      y_cW[e] = q_cW[e];
+      y_cN[e] = q_cN[e];
+      y_dE[e] = q_dE[e];
+      y_dN[e] = q_dN[e];
+    }
     float *qw_d = w_d + tau0, *qw_c = w_c + tau0;
     const int jb = tau0 + jo;
 #pragma unroll
@@ -303,14 +332,16 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       const int j = jb + e;
       const bool col_ok = (j >= 1) && (j <= m_);
       const bool act = row_ok && col_ok;
-      const float rv = n_rv, cW = n_cW, cN = n_cN, dE0 = n_dE0, dN0 = n_dN0;
+      const float rv = o_rv[e], cW = o_cW[e], cN = o_cN[e], dE0 = o_dE[e], dN0 = o_dN[e];
       float lw, le, ls, ln, iv;
       if (FAST) {
-        lw = lwU;
-        le = leU;
-        ls = (j == 1) ? lsB : cu;
-        ln = (j == m_) ? lsB : cu;
-        iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);
+        // every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform
+        // coefficient: cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).
+        lw = cu;
+        le = cu;
+        ls = cu;
+        ln = cu;
+        iv = zb ? ((j == 1) ? iv1 : ((j == m_) ? iv2 : iv0)) : iv0;
       } else {
         lw = c_lw.v[e];
         le = c_le.v[e];
@@ -318,11 +349,6 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
         ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;
         iv = c_iv.v[e];
       }
-      n_rv = q_rv[e + 1];
-      n_cW = q_cW[e + 1];
-      n_cN = q_cN[e + 1];
-      n_dE0 = q_dE[e + 1];
-      n_dN0 = q_dN[e + 1];
       const float prev = res;
       const float up16 = lane_minus16(prev, lane);  // (k-1, c): sweep k-1 at (i+1, j)
       const float dW = dpp_row_shr1(cW, prev);      // (k, c-1): sweep k   at (i-1, j)
