@@ -1,0 +1,90 @@
+"""GPU: the batched agent step (draw() loop on the device) vs the CPU draw-loop oracle, episode
+bookkeeping, masked reset, checkpoint round trip."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.draw_loop import OracleDrawLoop
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def envmod():
+    from rlfluidcontrol_amd import build, env
+    build.build()
+    return env
+
+
+@pytest.mark.parametrize("quirk", [0, 1])
+def test_agent_step_matches_draw_loop(envmod, quirk):
+    """parity mode: obs/reward/step counts of 5 agent steps are bit-identical to the oracle's
+    float32 restatement of clientCFD.pde:35-56 (incl. the optional Cd/Cl carry quirk)"""
+    res, Re = 8, 100
+    g = envmod.AFCEnv(num_envs=2, resolution=res, reynolds=Re, exact_sums=1, init_time=0.2, end_time=50.0,
+                      carry_quirk=quirk)
+    o = OracleDrawLoop(resolution=res, Re=Re, init_time=0.2, end_time=50.0, carry_quirk=bool(quirk))
+    rng = np.random.default_rng(7)
+    a = np.zeros((1, 2), np.float32)
+    for k in range(5):
+        og, rg, dg, ng = g.agent_step(np.tile(a, (2, 1)))
+        oo, ro, do, no = o.agent_step(a)
+        assert ng[0] == no[0] and ng[1] == no[0]
+        assert np.array_equal(og[0], oo[0]) and np.array_equal(og[1], oo[0]), (k, og, oo)
+        assert np.array_equal(rg[:1], ro) and dg[0] == do[0]
+        a = rng.uniform(-1, 1, (1, 2)).astype(np.float32)
+    assert ng[0] == 16
+    g.close()
+
+
+def test_episode_end_and_masked_reset(envmod):
+    g = envmod.AFCEnv(num_envs=3, resolution=8, reynolds=100, init_time=0.0, end_time=0.3)
+    z = np.zeros((3, 2), np.float32)
+    obs, rew, done, ns = g.agent_step(z)
+    assert list(ns) == [16, 16, 16] and not done.any()
+    obs, rew, done, ns = g.agent_step(z)
+    assert not done.any()
+    obs3, rew, done, ns = g.agent_step(z)  # t reaches 0.3 after 40 steps: 8 steps, no new request
+    assert list(ns) == [8, 8, 8] and done.all()
+    assert np.array_equal(obs3, obs)  # obs keeps the last completed window
+    t_before = g.t.copy()
+    g.reset(np.array([1, 0, 1], np.uint8))
+    t_after = g.t
+    assert t_after[0] == 0 and t_after[2] == 0 and t_after[1] == t_before[1]
+    obs, rew, done, ns = g.agent_step(z)
+    assert list(ns) == [16, 0, 16] and list(done) == [0, 1, 0]
+    u0, v0, p0 = g.get_state(0)
+    u2, v2, p2 = g.get_state(2)
+    assert np.array_equal(u0, u2) and np.array_equal(p0, p2)
+    g.close()
+
+
+def test_bdim_roundtrip(envmod, init_bdim, tmp_path):
+    g = envmod.AFCEnv(num_envs=2, resolution=24, reynolds=500)
+    g.set_reset_state(init_bdim["u"], init_bdim["v"], init_bdim["p"])
+    g.update2(np.array([[1.0, -1.0], [0.0, 0.0]], np.float32))
+    path = os.path.join(tmp_path, "s.bdim")
+    g.write(path, env_idx=0)
+    u, v, p = g.get_state(0)
+    h = envmod.AFCEnv(num_envs=1, resolution=24, reynolds=500)
+    h.resume(path)
+    u2, v2, p2 = h.get_state(0)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(p, p2)
+    g.close()
+    h.close()
+
+
+def test_developed_wake_fixture_is_a_fixed_point_class(envmod):
+    """the committed res-16 wake: stepping it stays bounded and sheds (Cl changes sign over a period)"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wake_res16_re100.npz"))
+    g = envmod.AFCEnv(num_envs=1, resolution=16, reynolds=100, init_time=0.0, end_time=1e9)
+    g.set_reset_state(z["u"], z["v"], z["p"])
+    cls = []
+    for _ in range(60):
+        obs, _, _, _ = g.agent_step(np.zeros((1, 2), np.float32))
+        cls.append(float(obs[0, 0]))
+    assert g.diverged()[0] == 0 and max(np.abs(cls)) < 2.0
+    assert min(cls) < -0.05 and max(cls) > 0.05
+    assert 1.0 < float(obs[0, 1]) < 2.5
+    g.close()
