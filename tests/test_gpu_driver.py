@@ -45,8 +45,13 @@ def test_episode_end_and_masked_reset(envmod):
     assert list(ns) == [16, 16, 16] and not done.any()
     obs, rew, done, ns = g.agent_step(z)
     assert not done.any()
-    obs3, rew, done, ns = g.agent_step(z)  # t reaches 0.3 after 40 steps: 8 steps, no new request
-    assert list(ns) == [8, 8, 8] and done.all()
+    obs3, rew, done, ns = g.agent_step(z)  # t reaches 0.3 before the third window completes
+    f32 = np.float32
+    t, n_end = f32(0), 0
+    while t < f32(0.3):  # float32 time bookkeeping of AFCCylinder.pde:56
+        t = f32(t + f32(f32(f32(0.0075) * f32(8)) / f32(8)))
+        n_end += 1
+    assert 32 < n_end < 48 and list(ns) == [n_end - 32] * 3 and done.all()
     assert np.array_equal(obs3, obs)  # obs keeps the last completed window
     t_before = g.t.copy()
     g.reset(np.array([1, 0, 1], np.uint8))
