@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,12 +40,12 @@ using afc::StepParams;
 // straightforward reference kernels.  One instantiation per CPL keeps each kernel's register
 // budget at 4 workgroups (16 waves) per CU.
 template <int CPL>
-__device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, double *sm,
-                                              afc::ShBcast *sh, float *lds) {
+__device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
+                                              double *sm, afc::ShBcast *sh, float *lds) {
   if constexpr (CPL == 0)
     afc::sim_step(P, e, a, b, sm, sh);
   else
-    afc::sim_step_v2<CPL>(P, e, a, b, sm, sh, lds);
+    afc::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
 }
 
 template <int CPL>
@@ -55,9 +56,11 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(StepParams P, con
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
-  step_dispatch<CPL>(P, e, a, b, sm, &sh, lds_dyn);
+  float pshift = P.sc[e].p_shift;
+  step_dispatch<CPL>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
   if (threadIdx.x == 0) {
     EnvScalars &s = P.sc[e];
+    s.p_shift = pshift;
     s.xi1_m = a;
     s.xi2_m = b;
     s.t += P.dt / P.resolution;  // AFCCylinder.pde:56
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(StepParams P, c
   bool got = false;
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
-    step_dispatch<CPL>(P, e, s.xi1_m, s.xi2_m, sm, &sh, lds_dyn);
+    step_dispatch<CPL>(P, e, s.xi1_m, s.xi2_m, &s.p_shift, sm, &sh, lds_dyn);
     ++steps;
     s.t += P.dt / P.resolution;
     s.force_x = sh.fx;
@@ -181,15 +184,17 @@ __global__ void k_vorticity(StepParams P, int env_idx, float *__restrict__ out) 
 __global__ void k_probes(StepParams P, const afc::SampleDev *__restrict__ ps, int num, float *__restrict__ out) {
   const int e = blockIdx.x;
   const float *p = P.p + (size_t)e * P.Ns;
+  const float sh = P.sc[e].p_shift;  // pending mean shift of the last projection (bdim_v2.h)
   const int m = P.m;
   for (int q = threadIdx.x; q < num; q += blockDim.x) {
     const afc::SampleDev sd = ps[q];
     const float *a = p + sd.base;
     float val;
     if (sd.exact)
-      val = a[0];
+      val = a[0] + sh;
     else
-      val = sd.s * (sd.t * a[m + 1] + (1 - sd.t) * a[m]) + (1 - sd.s) * (sd.t * a[1] + (1 - sd.t) * a[0]);
+      val = sd.s * (sd.t * (a[m + 1] + sh) + (1 - sd.t) * (a[m] + sh)) +
+            (1 - sd.s) * (sd.t * (a[1] + sh) + (1 - sd.t) * (a[0] + sh));
     out[(size_t)e * num + q] = val;
   }
 }
@@ -237,7 +242,15 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iter
   afc::Prof pf;
   pf.start(P);
   extern __shared__ float lds_dyn[];
-  const int it = afc::mg_solve(P, 0, sm, &l, pf, P.impl ? lds_dyn : nullptr);
+  int it;
+  if (P.impl == 0) {
+    it = afc::mg_solve(P, 0, sm, &l, pf);
+  } else {
+    afc::Lv L0v = afc::make_level(P, 0, 0);
+    L0v.d = P.u0y;
+    float xs;
+    it = afc::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+  }
   if (threadIdx.x == 0) {
     *iters = it;
     *linf = l;
@@ -772,6 +785,12 @@ int afc_get_field(afc_env *env, int env_idx, int which, float *out) {
     default: return fail(AFC_EINVAL, "afc_get_field: unknown field");
   }
   HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  if (which == AFC_FIELD_P) {  // apply the pending mean shift (p.plusEq(-mean), VectorField.pde:136)
+    EnvScalars s;
+    HIP_TRY(hipMemcpy(&s, P.sc + env_idx, sizeof(s), hipMemcpyDeviceToHost));
+    if (s.p_shift != 0.f)
+      for (int k = 0; k < P.N; ++k) out[k] = out[k] + s.p_shift;
+  }
   return AFC_OK;
 }
 int afc_set_field(afc_env *env, int env_idx, int which, const float *in) {
@@ -789,6 +808,11 @@ int afc_set_field(afc_env *env, int env_idx, int which, const float *in) {
     default: return fail(AFC_EINVAL, "afc_set_field: field is read-only or unknown");
   }
   HIP_TRY(hipMemcpy(dst, in, (size_t)P.N * sizeof(float), hipMemcpyHostToDevice));
+  if (which == AFC_FIELD_P) {
+    const float zero = 0.f;
+    HIP_TRY(hipMemcpy(reinterpret_cast<char *>(P.sc + env_idx) + offsetof(EnvScalars, p_shift), &zero, sizeof(float),
+                      hipMemcpyHostToDevice));
+  }
   return AFC_OK;
 }
 

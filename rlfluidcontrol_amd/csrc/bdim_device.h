@@ -575,7 +575,7 @@ __device__ inline int phase_project(const StepParams &P, size_t e, double *sm, f
 }
 
 // Body.pressForce(flow.p).mult(-1) of the main cylinder (Body.pde:296-303, AFCCylinder.pde:58)
-__device__ inline void eval_force(const StepParams &P, const float *p, float *fxo, float *fyo) {
+__device__ inline void eval_force(const StepParams &P, const float *p, float shift, float *fxo, float *fyo) {
   float px = 0, py = 0;
   const int m = P.m;
   for (int s = 0; s < P.nseg; ++s) {
@@ -583,9 +583,10 @@ __device__ inline void eval_force(const StepParams &P, const float *p, float *fx
     const float *a = p + sd.base;
     float val;
     if (sd.exact) {
-      val = a[0];
+      val = a[0] + shift;
     } else {
-      val = sd.s * (sd.t * a[m + 1] + (1 - sd.t) * a[m]) + (1 - sd.s) * (sd.t * a[1] + (1 - sd.t) * a[0]);
+      val = sd.s * (sd.t * (a[m + 1] + shift) + (1 - sd.t) * (a[m] + shift)) +
+            (1 - sd.s) * (sd.t * (a[1] + shift) + (1 - sd.t) * (a[0] + shift));
     }
     const float pdl = val * P.seg_l[s];
     px += pdl * P.seg_nx[s];
@@ -636,7 +637,7 @@ __device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, floa
   }
   if (threadIdx.x == 0) {
     float fx, fy;
-    eval_force(P, P.p + eo, &fx, &fy);
+    eval_force(P, P.p + eo, 0.f, &fx, &fy);
     sh->fx = fx;
     sh->fy = fy;
     sh->it0 = it0;

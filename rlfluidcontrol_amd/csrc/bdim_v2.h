@@ -379,7 +379,7 @@ __device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc
 // need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
 template <bool HASC>
 __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm, float *rr_out,
-                                    float *linf_out) {
+                                    float *linf_out, Prof &pf, float *xsum_out = nullptr) {
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   float *rr = lds + 32, *dr = rr + kRing * m, *carry = dr + kRing * m, *dummy = carry + 4 * m + 32;
   const int tid = threadIdx.x;
@@ -387,7 +387,7 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
   const int mc = Cc.m;
   const int rstep = kThreads / m, cstep = kThreads - rstep * m;  // flat (row, col) stepping by kThreads
   const int r0 = tid / m, c0 = tid - r0 * m;
-  double rr_part = 0;
+  double rr_part = 0, xs_part = 0;
   float linf = 0.f;
   __syncthreads();
   for (int q = tid; q < 4 * m + 32; q += kThreads) carry[q] = 0.f;
@@ -435,6 +435,7 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
     }
     loaded = hi;
     __syncthreads();
+    if (need_r) pf.mark(PF_UP0);
     if (tid < 64) {
       const bool special = (I0 + 16 >= D.sp_i0) && (I0 - 3 <= D.sp_i1);
       if (special)
@@ -443,6 +444,7 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
         gs_march<true>(F, rr, dr, carry, dummy, I0);
     }
     __syncthreads();
+    if (need_r) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
     const bool sp_exit = (e1 + 1 >= D.sp_i0) && (e0 - 1 <= D.sp_i1);
@@ -477,7 +479,9 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
           // x += d on the cell and on the ghosts that mirror it (MG.pde:95 after d.setBC())
           float xo = F.x[kk];
           if (HASC) xo = xo + prolong_at(Cc.x, mc, g, j, n_, m_);
-          F.x[kk] = xo + d;
+          const float xnew = xo + d;
+          F.x[kk] = xnew;
+          if (need_r) xs_part += (double)xnew;
           const bool gi0 = (g == 1), gi1 = (g == n_), gj0 = (j == 1), gj1 = (j == m_);
           if (gi0 | gi1 | gj0 | gj1) {
             const float dp = HASC ? prolong_at(Cc.x, mc, g, j, n_, m_) : 0.f;
@@ -507,56 +511,290 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
       }
     }
     __syncthreads();  // the next strip's fill re-uses ring slots this exit has just read
+    if (need_r) pf.mark(PF_INC0);
   }
   if (need_r) {
     *rr_out = (float)block_sum_d(rr_part, sm);
     *linf_out = block_max_f(linf, sm);
+    if (xsum_out) *xsum_out = (float)block_sum_d(xs_part, sm);
   }
 }
 
-// MGsolver (MG.pde:30-38) with the fused ascending leg; descending leg = reference kernels
-__device__ inline int mg_solve_v2(const StepParams &P, size_t e, double *sm, float *linf_out, Prof &pf, float *lds) {
+__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
+
+// ---------------------------------------------------------------------------------------------
+// Fused head of the pressure solve on the finest level (MG.pde:51 + first smooth(0) + restrict):
+//   r0 = div(u) - A (p+s)      s = pending mean shift of the previous projection (see project_v2)
+//   d  = r0*inv; d.setBC();    pout = (p+s) + d   (all cells incl. ghosts);   r = r0 - A d
+//   r1 = restrict(r)           (interior; coarse ghosts are never read)
+// Streamed in blocks of 14 rows: r0 of 16 rows goes through an LDS tile, every thread then owns
+// a 2x4 patch (one restriction pair of rows, two coarse cells).  u, v, p are read once, p and r
+// written once.  pin and pout are different buffers (rows a-2.. of pin are still needed when rows
+// ..a-1 of pout are written).
+// ---------------------------------------------------------------------------------------------
+__device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift,
+                                      float *lds) {
+  const int n = L0.n, m = L0.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  const LevelDesc &D = *L0.desc;
+  float *pout = L0.x, *r = L0.r;
+  float *t0 = lds + 8;  // r0 tile: 16 rows, pitch m
+  const int tid = threadIdx.x;
+  const int m1 = L1.m;
+  for (int q = tid; q < L1.n * L1.m; q += kThreads) L1.x[q] = 0.f;  // MG.pde:56
+  const int R = 14;
+  for (int a = 1; a <= n_; a += R) {
+    const bool sp = (a + R + 1 >= D.sp_i0) && (a - 2 <= D.sp_i1);
+    __syncthreads();
+    // ---- step 1: r0 for rows a-1 .. a+14 ----
+    for (int q = tid; q < 16 * CPR; q += kThreads) {
+      const int t = q / CPR, c4 = q - t * CPR;
+      const int g = a - 1 + t, j = 1 + 4 * c4;
+      if (g < 1 || g > n_) continue;
+      const int k = g * m + j;
+      const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
+      const float uyn = uy[k + 4];
+      const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
+      const float psl = pin[k - 1], pnr = pin[k + 4];
+      F4 lw, le, ls;
+      float ln4;
+      if (sp) {
+        lw = load4u(L0.lx + k);
+        le = load4u(L0.lx + k + m);
+        ls = load4u(L0.ly + k);
+        ln4 = L0.ly[k + 4];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
+        ln4 = D.cu;
+      }
+      F4 r0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
+        const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
+        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lwv + lev + lsv + lnv);
+        const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
+        const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift, pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
+        const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
+        r0.v[e] = div - ap;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t0[t * m + j + e] = r0.v[e];
+    }
+    __syncthreads();
+    // ---- step 2: one 2x4 patch per thread ----
+    for (int q = tid; q < 7 * CPR; q += kThreads) {
+      const int pr = q / CPR, c4 = q - pr * CPR;
+      const int g = a + 2 * pr, j = 1 + 4 * c4;
+      if (g > n_) continue;
+      // d = r0*inv on rows g-1..g+2, cols j-1..j+4 with the setBC mirror (clamp into the interior)
+      float dd[4][6];
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        int gg = g - 1 + a4;
+        gg = gg < 1 ? 1 : (gg > n_ ? n_ : gg);
+        const float *row = t0 + (gg - (a - 1)) * m;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          int jj = j - 1 + b;
+          jj = jj < 1 ? 1 : (jj > m_ ? m_ : jj);
+          float iv;
+          if (sp) {
+            iv = L0.inv[gg * m + jj];
+          } else {
+            iv = D.invtab[3 * ((gg == 1) ? 1 : ((gg == n_) ? 2 : 0)) + ((jj == 1) ? 1 : ((jj == m_) ? 2 : 0))];
+          }
+          dd[a4][b] = row[jj] * iv;  // MG.pde:80
+        }
+      }
+      float rn[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gg = g + h, k = gg * m + j;
+        F4 lw, le, ls;
+        float ln4;
+        if (sp) {
+          lw = load4u(L0.lx + k);
+          le = load4u(L0.lx + k + m);
+          ls = load4u(L0.ly + k);
+          ln4 = L0.ly[k + 4];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
+          ln4 = D.cu;
+        }
+        const F4 pc = load4u(pin + k);
+        const float *r0row = t0 + (gg - (a - 1)) * m + j;
+        F4 xo, ro;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+          const float diag = -(lwv + lev + lsv + lnv);
+          const float d = dd[1 + h][1 + e];
+          const float ad = d * diag + dd[h][1 + e] * lwv + dd[2 + h][1 + e] * lev + dd[1 + h][e] * lsv +
+                           dd[1 + h][2 + e] * lnv;  // PoissonMatrix.pde:57-61
+          rn[h][e] = r0row[e] - ad;                  // MG.pde:96
+          ro.v[e] = rn[h][e];
+          xo.v[e] = (pc.v[e] + shift) + d;           // MG.pde:95
+        }
+        store4u(pout + k, xo);
+        store4u(r + k, ro);
+        // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+        if (c4 == 0) pout[k - 1] = (pin[k - 1] + shift) + dd[1 + h][1];
+        if (c4 == CPR - 1) pout[k + 4] = (pin[k + 4] + shift) + dd[1 + h][4];
+        const bool top = (gg == 1), bot = (gg == n_);
+        if (top || bot) {
+          const int kg = (top ? 0 : (n - 1)) * m + j;
+          const F4 pg = load4u(pin + kg);
+          F4 xg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + dd[1 + h][1 + e];
+          store4u(pout + kg, xg);
+          if (c4 == 0) pout[kg - 1] = (pin[kg - 1] + shift) + dd[1 + h][1];
+          if (c4 == CPR - 1) pout[kg + 4] = (pin[kg + 4] + shift) + dd[1 + h][4];
+        }
+      }
+      // restrict (MG.pde:124-137): sum of the 2x2 children, reference order
+      const int ci = (g - 1) / 2 + 1, cj = (j - 1) / 2 + 1;
+      L1.r[ci * m1 + cj] = rn[0][0] + rn[0][1] + rn[1][0] + rn[1][1];
+      L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
+    }
+  }
+  __syncthreads();
+}
+
+// MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
+// coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
+__device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
+                                  const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
+                                  Prof &pf, float *lds, bool fused_head = true) {
   const int kc = P.nlev - 1;
   int iter = 0;
-  const Lv L0 = make_level(P, e, 0);
-  float linf = 0.f;
+  float linf = 0.f, xsum = 0.f;
   while (iter < P.mg_max_iters) {
     ++iter;
     for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
-      const Lv F = make_level(P, e, l), Cc = make_level(P, e, l + 1);
-      mg_dinv(F);  // smooth(0)
-      mg_increment(F);
-      mg_restrict(F, Cc);
+      const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      if (l == 0 && iter == 1 && fused_head) {
+        mg_down0_fused(P, L0, Cc, ux, uy, pin, shift, lds);
+      } else {
+        mg_dinv(F);  // smooth(0)
+        mg_increment(F);
+        mg_restrict(F, Cc);
+      }
       pf.mark(l == 0 ? PF_DOWN0 : PF_COARSE_DOWN);
     }
     float rr = 0.f;
     {
       const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
-      mg_up_smooth<false>(Lk, Lk, false, lds, sm, &rr, &linf);
+      mg_up_smooth<false>(Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(PF_COARSE_GS);
     }
     for (int l = kc - 1; l >= 0; --l) {
-      const Lv F = make_level(P, e, l), Cc = make_level(P, e, l + 1);
-      mg_up_smooth<true>(F, Cc, l == 0, lds, sm, &rr, &linf);
-      pf.mark(l == 0 ? PF_GS0 : PF_COARSE_GS);
+      const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      mg_up_smooth<true>(F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
+      pf.mark(l == 0 ? PF_RR : PF_COARSE_GS);
     }
     if (P.exact_sums) rr = seq_inner(L0, sm);
-    pf.mark(PF_RR);
     if (rr < P.mg_tol) break;
   }
   *linf_out = linf;
+  *xsum_out = xsum;
   return iter;
 }
 
+// Tail of u.project (VectorField.pde:136-140) [+ the Heun average of BDIM.update2, BDIM.pde:95-96]:
+//   p' = p + s (s = -sum(p)/N);  u -= c * grad p';  u.setBC();  [A = (u + us)/2]
+// p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
+// shift; every reader of p (next solve's head, force, probes, field export) forms p+s itself --
+// the same float32 addition the reference's plusEq performs, so the bits are identical.
+template <bool HEUN>
+__device__ inline void project_tail_v2(const StepParams &P, const float *__restrict__ p, float shift, float *vx,
+                                       float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
+                                       float *ax, float *ay) {
+  const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  for (int q = threadIdx.x; q < n_ * CPR; q += kThreads) {
+    const int g = q / CPR + 1, c4 = q - (g - 1) * CPR;
+    const int k = g * m + 1 + 4 * c4;
+    const F4 pc = load4u(p + k), pw = load4u(p + k - m);
+    const float psl = p[k - 1];
+    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k), cx4 = load4u(P.cx + k), cy4 = load4u(P.cy + k);
+    F4 un, vn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pcs = pc.v[e] + shift, pws = pw.v[e] + shift;
+      const float pss = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift;
+      const float gx = pcs - pws, gy = pcs - pss;                // Field.pde:76-77
+      un.v[e] = u4.v[e] + cx4.v[e] * (gx * -1.f);                // VectorField.pde:138
+      vn.v[e] = v4.v[e] + cy4.v[e] * (gy * -1.f);
+    }
+    store4u(vx + k, un);
+    store4u(vy + k, vn);
+    if (HEUN) {  // cells on the lines setBC rewrites are redone below
+      const F4 b4 = load4u(ox + k), d4 = load4u(oy + k);
+      F4 a4, e4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a4.v[e] = (un.v[e] + b4.v[e]) * 0.5f;
+        e4.v[e] = (vn.v[e] + d4.v[e]) * 0.5f;
+      }
+      store4u(ax + k, a4);
+      store4u(ay + k, e4);
+    }
+  }
+  __syncthreads();
+  setbc_vel(P, vx, vy);
+  if (HEUN) {  // lines touched by setBC: rows 0,1,n-1 and columns 0,1,m-1
+    for (int q = threadIdx.x; q < 3 * m + 3 * n; q += kThreads) {
+      int k;
+      if (q < 3 * m) {
+        const int rsel = q / m, j = q - rsel * m;
+        k = ((rsel == 0) ? 0 : ((rsel == 1) ? 1 : (n - 1))) * m + j;
+      } else {
+        const int qq = q - 3 * m, csel = qq / n, i = qq - csel * n;
+        k = i * m + ((csel == 0) ? 0 : ((csel == 1) ? 1 : (m - 1)));
+      }
+      ax[k] = (vx[k] + ox[k]) * 0.5f;
+      ay[k] = (vy[k] + oy[k]) * 0.5f;
+    }
+    __syncthreads();
+  }
+}
+
+// u.project(c, p) (VectorField.pde:130-143).  pin holds the previous pressure (+ pending shift),
+// the result is left in pout (a different buffer) with a new pending shift *shift_io.
+template <int C, bool HEUN>
+__device__ inline int project_v2(const StepParams &P, size_t e, float *vx, float *vy, const float *pin, float *pout,
+                                 float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
+                                 float *linf_out, Prof &pf, float *lds) {
+  const size_t eo = e * (size_t)P.Ns;
+  Lv L0 = make_level(P, e, 0);
+  L0.x = pout;
+  L0.d = P.u0y + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
+  float xsum = 0.f;
+  const int iters = mg_solve_v2(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
+  float psum = xsum;
+  if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
+  const float shift = -1 * psum / (float)((P.n - 2) * (P.m - 2));  // VectorField.pde:136
+  project_tail_v2<HEUN>(P, pout, shift, vx, vy, ox, oy, ax, ay);
+  *shift_io = shift;
+  pf.mark(PF_PROJECT);
+  return iters;
+}
+
 template <int C>
-__device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, double *sm, ShBcast *sh,
-                                   float *lds) {
+__device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
+                                   ShBcast *sh, float *lds) {
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
   const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
   float *Ax = P.ux + eo, *Ay = P.uy + eo, *Bx = P.usx + eo, *By = P.usy + eo, *Cx = P.fx + eo, *Cy = P.fy + eo;
   float *scratch = P.u0x + eo;
+  float *p0 = P.p + eo, *p1 = P.d + eo;  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
+  float shift = *pshift;
   Prof pf;
   pf.start(P);
   // predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP
@@ -566,7 +804,8 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   pf.mark(PF_FORCING);
   setbc_vel(P, Bx, By);
   pf.mark(PF_SETBC);
-  const int it0 = project_vel(P, e, Bx, By, sm, &l0, pf, lds);
+  const int it0 = project_v2<C, false>(P, e, Bx, By, p0, p1, &shift, nullptr, nullptr, nullptr, nullptr, sm, &l0, pf,
+                                       lds);
   // corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; u = (u+us)/2
   advdif_v2<C>(P, Bx, By, Ax, Ay, Cx, Cy, lds);
   pf.mark(PF_ADVDIF);
@@ -574,14 +813,11 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   pf.mark(PF_FORCING);
   setbc_vel(P, Cx, Cy);
   pf.mark(PF_SETBC);
-  const int it1 = project_vel(P, e, Cx, Cy, sm, &l1, pf, lds);
-  for (int k = threadIdx.x; k < P.N; k += kThreads) {  // BDIM.pde:95-96, whole array, no setBC
-    Ax[k] = (Cx[k] + Bx[k]) * 0.5f;
-    Ay[k] = (Cy[k] + By[k]) * 0.5f;
-  }
+  const int it1 = project_v2<C, true>(P, e, Cx, Cy, p1, p0, &shift, Bx, By, Ax, Ay, sm, &l1, pf, lds);
+  *pshift = shift;
   if (threadIdx.x == 0) {
     float fx, fy;
-    eval_force(P, P.p + eo, &fx, &fy);
+    eval_force(P, p0, shift, &fx, &fy);
     sh->fx = fx;
     sh->fy = fy;
     sh->it0 = it0;
