@@ -215,6 +215,7 @@ __device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byt
   __builtin_memcpy(&r, p, 16);
   return r;
 }
+__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
 
 // LDS layout used by the smoother (floats): [pad 32][r ring 24*m][d ring 24*m][carry 4*m][pad 32][dummy 64]
 __device__ __forceinline__ int gs_lds_floats(int m) { return 32 + (2 * kRing + 4) * m + 32 + 64; }
@@ -389,6 +390,8 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
   const int r0 = tid / m, c0 = tid - r0 * m;
   double rr_part = 0, xs_part = 0;
   float linf = 0.f;
+  const int CPR = m_ >> 2;
+  const bool chunked = ((m_ & 3) == 0);
   __syncthreads();
   for (int q = tid; q < 4 * m + 32; q += kThreads) carry[q] = 0.f;
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
@@ -396,6 +399,67 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
     // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
     const int hi = I0 + 16;
     const bool sp_fill = (hi + 1 >= D.sp_i0) && (loaded <= D.sp_i1);
+    if (chunked) {
+      // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
+      const int nrow = hi - loaded;
+      for (int q = tid; q < nrow * CPR; q += kThreads) {
+        const int t = q / CPR, c4 = q - t * CPR;
+        const int g = loaded + 1 + t, j = 1 + 4 * c4;
+        const int sl = (g % kRing) * m + j;
+        F4 rv, dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv.v[e] = dv.v[e] = 0.f;
+        if (g <= n_) {
+          const int kk = g * m + j;
+          rv = load4u(F.r + kk);
+          F4 lw, le, ls, iv;
+          float ln4;
+          if (sp_fill) {
+            lw = load4u(F.lx + kk);
+            le = load4u(F.lx + kk + m);
+            ls = load4u(F.ly + kk);
+            ln4 = F.ly[kk + 4];
+            iv = load4u(F.inv + kk);
+          } else {
+            float a0, a1, a2, a3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              coef_analytic(D, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
+              lw.v[e] = a0;
+              le.v[e] = a1;
+              ls.v[e] = a2;
+              if (e == 3) ln4 = a3;
+            }
+          }
+          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+            const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+            const float *xa = Cc.x + ((g - 1) / 2 + 1) * mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
+            const float *xw = Cc.x + ((gw - 1) / 2 + 1) * mc + 2 * c4;
+            const float *xe = Cc.x + ((ge - 1) / 2 + 1) * mc + 2 * c4;
+            const float a1 = xa[1], a2 = xa[2];
+            const float a0 = (c4 == 0) ? a1 : xa[0], a3 = (c4 == CPR - 1) ? a2 : xa[3];
+            const float w1 = xw[1], w2 = xw[2], e1 = xe[1], e2 = xe[2];
+            const float dc[4] = {a1, a1, a2, a2}, dw[4] = {w1, w1, w2, w2}, de[4] = {e1, e1, e2, e2};
+            const float ds[4] = {a0, a1, a1, a2}, dn[4] = {a1, a2, a2, a3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+              const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+              rv.v[e] = rv.v[e] - (dc[e] * diag + dw[e] * lw.v[e] + de[e] * le.v[e] + ds[e] * ls.v[e] + dn[e] * lnv);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rr[sl + e] = rv.v[e];
+          dr[sl + e] = dv.v[e];
+        }
+        if (c4 == 0) dr[sl - 1] = 0.f;        // ghost columns of d0 read as zero
+        if (c4 == CPR - 1) dr[sl + 4] = 0.f;
+      }
+    } else
     {
       int g = loaded + 1 + r0, j = c0;
       while (g <= hi) {
@@ -448,6 +512,96 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
     const bool sp_exit = (e1 + 1 >= D.sp_i0) && (e0 - 1 <= D.sp_i1);
+    if (chunked) {
+      const int nrow = e1 - e0 + 1;
+      for (int q = tid; q < nrow * CPR; q += kThreads) {
+        const int t = q / CPR, c4 = q - t * CPR;
+        const int g = e0 + t, j = 1 + 4 * c4, kk = g * m + j;
+        const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+        const int sl = (g % kRing) * m + j;
+        const F4 x4 = load4u(F.x + kk);
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HASC) {
+          const float *xa = Cc.x + ((g - 1) / 2 + 1) * mc + 2 * c4;
+          const float a1 = xa[1], a2 = xa[2];
+          dp[0] = a1;
+          dp[1] = a1;
+          dp[2] = a2;
+          dp[3] = a2;
+        }
+        float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
+#pragma unroll
+        for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
+        if (c4 == 0) d6[0] = d6[1];
+        if (c4 == CPR - 1) d6[5] = d6[4];
+        F4 xn;
+        if (need_r) {
+          const float *dwp = dr + (gw % kRing) * m + j, *dep = dr + (ge % kRing) * m + j;
+          F4 lw, le, ls;
+          float ln4;
+          if (sp_exit) {
+            lw = load4u(F.lx + kk);
+            le = load4u(F.lx + kk + m);
+            ls = load4u(F.ly + kk);
+            ln4 = F.ly[kk + 4];
+          } else {
+            float a0, a1, a2, a3, a4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              coef_analytic(D, g, j + e, n_, m_, a0, a1, a2, a3, a4);
+              lw.v[e] = a0;
+              le.v[e] = a1;
+              ls.v[e] = a2;
+              if (e == 3) ln4 = a3;
+            }
+          }
+          F4 rn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+            const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+            const float d = d6[1 + e];
+            rn.v[e] = rr[sl + e] - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
+            const float pr = rn.v[e] * rn.v[e];
+            rr_part += (double)pr;
+            linf = jmax(linf, jabs(rn.v[e]));
+          }
+          store4u(F.r + kk, rn);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xo = x4.v[e];
+          if (HASC) xo = xo + dp[e];
+          xn.v[e] = xo + d6[1 + e];
+          if (need_r) xs_part += (double)xn.v[e];
+        }
+        store4u(F.x + kk, xn);
+        // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
+#define GHOST1(KG, E)                     \
+  {                                       \
+    float xg = F.x[KG];                   \
+    if (HASC) xg = xg + dp[E];            \
+    F.x[KG] = xg + d6[1 + (E)];           \
+  }
+        if (c4 == 0) GHOST1(kk - 1, 0)
+        if (c4 == CPR - 1) GHOST1(kk + 4, 3)
+        if (g == 1 || g == n_) {
+          const int kg = ((g == 1) ? 0 : (n - 1)) * m + j;
+          const F4 xg4 = load4u(F.x + kg);
+          F4 xgn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float xg = xg4.v[e];
+            if (HASC) xg = xg + dp[e];
+            xgn.v[e] = xg + d6[1 + e];
+          }
+          store4u(F.x + kg, xgn);
+          if (c4 == 0) GHOST1(kg - 1, 0)
+          if (c4 == CPR - 1) GHOST1(kg + 4, 3)
+        }
+#undef GHOST1
+      }
+    } else
     {
       int g = e0 + r0, j = c0;
       while (g <= e1) {
@@ -519,8 +673,6 @@ __device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, floa
     if (xsum_out) *xsum_out = (float)block_sum_d(xs_part, sm);
   }
 }
-
-__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
 
 // ---------------------------------------------------------------------------------------------
 // Fused head of the pressure solve on the finest level (MG.pde:51 + first smooth(0) + restrict):
