@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--res", type=int, default=16, help="resolution: grid = 16*res x 8*res")
     ap.add_argument("--reynolds", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger-us", type=int, default=0)
     ap.add_argument("--init", default=os.path.join(ROOT, "tests", "golden", "wake_res16_re100.npz"),
                     help="developed-wake state to start from (falls back to the free stream)")
     args = ap.parse_args()
@@ -97,7 +98,8 @@ def main():
     from rlfluidcontrol_amd import build, env as envmod
     build.build()
     E = args.envs
-    g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank)
+    g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank,
+                      stagger_us=args.stagger_us)
     init_used = "free stream"
     if args.init and os.path.exists(args.init):
         z = np.load(args.init)

@@ -93,7 +93,8 @@ typedef struct afc_config {
                            whole step bit-identical to the reference arithmetic; 0 (default): tree sums */
   int32_t impl;         /* 2 (default): optimised kernels; 0: the straightforward reference kernels
                            (same arithmetic; kept for A/B timing and bisecting) */
-  int32_t reserved[5];
+  int32_t stagger_us;   /* start offset between the (up to 4) envs sharing a CU, microseconds (0 = none) */
+  int32_t reserved[4];
 } afc_config;
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */

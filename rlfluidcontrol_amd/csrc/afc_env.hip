@@ -49,8 +49,10 @@ __device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, flo
 }
 
 template <int CPL>
-__global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(StepParams P, const float *__restrict__ xi_m,
+__global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams *__restrict__ Pp,
+                                                               const float *__restrict__ xi_m,
                                                                float *__restrict__ force) {
+  const StepParams &P = *Pp;  // parameters live in device memory: phase functions take them by reference
   __shared__ double sm[afc::kThreads];
   __shared__ afc::ShBcast sh;
   extern __shared__ float lds_dyn[];
@@ -81,14 +83,20 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(StepParams P, con
 
 // The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
 template <int CPL>
-__global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(StepParams P, const float *__restrict__ action,
+__global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParams *__restrict__ Pp,
+                                                                 const float *__restrict__ action,
                                                                  float *__restrict__ obs, float *__restrict__ reward,
                                                                  uint8_t *__restrict__ done, int *__restrict__ nsteps,
                                                                  int max_steps) {
+  const StepParams &P = *Pp;
   __shared__ double sm[afc::kThreads];
   __shared__ afc::ShBcast sh;
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
+  if (P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
+    const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> P.stagger_shift) & 3);
+    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
+  }
   EnvScalars s = P.sc[e];  // every thread keeps an identical private copy (uniform control flow)
   const float a1 = action[2 * e], a2 = action[2 * e + 1];
   s.xi1 = a1;  // clientCFD.pde:51-54
@@ -277,6 +285,8 @@ struct afc_env {
   int32_t *d_i32 = nullptr;
   long long *d_stamps = nullptr;
   size_t lds_bytes = 0;
+  StepParams *d_P = nullptr;  // device copy of P for the step kernels
+  bool p_dirty = true;
   int cpl = 0;  // kernel instantiation: columns per lane (0 = reference kernels)
   std::vector<int> level_off;
   afc::SampleDev *d_probes = nullptr;
@@ -315,6 +325,14 @@ afc::SampleDev to_dev(const afc::PressSample &s, int m) {
   d.t = s.t;
   d.exact = s.exact;
   return d;
+}
+
+int sync_params(afc_env *env) {
+  if (!env->p_dirty) return AFC_OK;
+  HIP_TRY(hipMemcpyAsync(env->d_P, &env->P, sizeof(StepParams), hipMemcpyHostToDevice, env->stream));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  env->p_dirty = false;
+  return AFC_OK;
 }
 
 int launch_check(const char *what) {
@@ -413,6 +431,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.carry_quirk = cfg->carry_quirk;
   P.exact_sums = cfg->exact_sums;
   P.impl = cfg->impl;
+  P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
+  P.stagger_shift = (cfg->stagger_us >> 20) & 15;  // experimental: which block-index bits pick the phase
   P.adv_rows = (sf.m <= 130) ? 16 : 8;
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
@@ -506,6 +526,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_alloc(env, &env->d_f1, E);
   if (!rc) rc = dev_alloc(env, &env->d_u8, E);
   if (!rc) rc = dev_alloc(env, &env->d_i32, E * 2);
+  if (!rc) rc = dev_alloc(env, &env->d_P, (size_t)1);
   if (!rc) rc = dev_alloc(env, &env->d_stamps, (size_t)32);
   if (!rc && hipMemset(env->d_stamps, 0, 32 * sizeof(long long)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (rc) {
@@ -663,8 +684,9 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
     dxi = env->d_in;
     dforce = env->d_f2;
   }
+  if (int rcp = sync_params(env)) return rcp;
   switch (env->cpl) {
-#define LAUNCH(c) case c: hipLaunchKernelGGL(k_sim_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, env->P, dxi, dforce); break
+#define LAUNCH(c) case c: hipLaunchKernelGGL(k_sim_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break
     LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
 #undef LAUNCH
   }
@@ -701,8 +723,9 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   const float per = env->P.dt / env->cfg.resolution;
   const int warm = (int)(env->cfg.init_time / per);
   const int max_steps = (warm > 0 ? warm : 0) + 2 * env->cfg.substeps + 8;
+  if (int rcp = sync_params(env)) return rcp;
   switch (env->cpl) {
-#define LAUNCH(c) case c: hipLaunchKernelGGL(k_agent_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, env->P, dact, dobs, drew, ddone, dns, max_steps); break
+#define LAUNCH(c) case c: hipLaunchKernelGGL(k_agent_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break
     LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
 #undef LAUNCH
   }
@@ -886,6 +909,7 @@ int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count) 
   }
   HIP_TRY(hipMemset(env->d_stamps, 0, 32 * sizeof(long long)));
   env->P.stamps = enable ? env->d_stamps : nullptr;
+  env->p_dirty = true;
   return AFC_OK;
 }
 

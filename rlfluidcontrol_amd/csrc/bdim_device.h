@@ -80,6 +80,8 @@ struct StepParams {
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
   // v2 path
+  int stagger_shift;
+  int stagger_ticks;   // start delay (100 MHz ticks) per workgroup phase: de-synchronises the envs of a CU
   int impl;            // 0 = v1 reference kernels, 2 = optimised kernels
   int adv_rows;        // rows per LDS tile block in advdif_v2
   const int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing

@@ -223,7 +223,12 @@ __device__ __forceinline__ int gs_lds_floats(int m) { return 32 + (2 * kRing + 4
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
 __device__ __forceinline__ void coef_analytic(const LevelDesc &D, int i, int j, int n_, int m_, float &lw, float &le,
                                               float &ls, float &ln, float &iv) {
-  const float b = D.zero_bnd ? 0.f : D.cu;
+  if (!D.zero_bnd) {  // finest level: boundary faces keep c = dt, inv is the same everywhere
+    lw = le = ls = ln = D.cu;
+    iv = D.invtab[0];
+    return;
+  }
+  const float b = 0.f;
   lw = (i == 1) ? b : D.cu;
   le = (i == n_) ? b : D.cu;
   ls = (j == 1) ? b : D.cu;
@@ -273,16 +278,16 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
   const bool wd_lane = row_ok && (k == 3);
   const bool wc_lane = (c == 15);
   float *const dmy = dummy + lane;
-  // LDS operands of the four steps of a chunk are fetched one chunk ahead (<= 7 steps early: still
-  // far inside the hazard margins above)
-  float o_rv[4], o_cW[4], o_cN[4], o_dE[4], o_dN[4], y_rv[4], y_cW[4], y_cN[4], y_dE[4], y_dN[4];
+  // LDS operands of the four steps of a chunk are fetched at the end of the previous chunk
+  // (<= 4 steps early: far inside the hazard margins above)
+  float o_rv[4], o_cW[4], o_cN[4], o_dE[4], o_dN[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    y_rv[e] = p_rv[e];
-    y_cW[e] = p_cW[e];
-    y_cN[e] = p_cN[e];
-    y_dE[e] = p_dE[e];
-    y_dN[e] = p_dN[e];
+    o_rv[e] = p_rv[e];
+    o_cW[e] = p_cW[e];
+    o_cN[e] = p_cN[e];
+    o_dE[e] = p_dE[e];
+    o_dN[e] = p_dN[e];
   }
   F4 c_lw, c_le, c_ls, c_iv, x_lw, x_le, x_ls, x_iv;
   float c_ln4 = 0.f, x_ln4 = 0.f;
@@ -310,22 +315,6 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
     }
     const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4,
                 *q_dN = p_dN + tau0 + 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o_rv[e] = y_rv[e];
-      o_cW[e] = y_cW[e];
-      o_cN[e] = y_cN[e];
-      o_dE[e] = y_dE[e];
-      o_dN[e] = y_dN[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      y_rv[e] = q_rv[e];
-      y_cW[e] = q_cW[e];
-      y_cN[e] = q_cN[e];
-      y_dE[e] = q_dE[e];
-      y_dN[e] = q_dN[e];
-    }
     float *qw_d = w_d + tau0, *qw_c = w_c + tau0;
     const int jb = tau0 + jo;
 #pragma unroll
@@ -363,6 +352,14 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       *a_d = res;
       *a_c = res;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // operands of the next chunk (issued after this chunk's LDS writes)
+      o_rv[e] = q_rv[e];
+      o_cW[e] = q_cW[e];
+      o_cN[e] = q_cN[e];
+      o_dE[e] = q_dE[e];
+      o_dN[e] = q_dN[e];
+    }
   }
 #undef GS_CHUNK
 }
@@ -378,8 +375,8 @@ __device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc
 //   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
 // streamed strip by strip: r (and p on the finest level) cross HBM once, d never leaves LDS.
 // need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
-template <bool HASC>
-__device__ inline void mg_up_smooth(const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm, float *rr_out,
+__device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                    float *rr_out,
                                     float *linf_out, Prof &pf, float *xsum_out = nullptr) {
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   float *rr = lds + 32, *dr = rr + kRing * m, *carry = dr + kRing * m, *dummy = carry + 4 * m + 32;
@@ -755,6 +752,8 @@ __device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const L
           float iv;
           if (sp) {
             iv = L0.inv[gg * m + jj];
+          } else if (!D.zero_bnd) {
+            iv = D.invtab[0];
           } else {
             iv = D.invtab[3 * ((gg == 1) ? 1 : ((gg == n_) ? 2 : 0)) + ((jj == 1) ? 1 : ((jj == m_) ? 2 : 0))];
           }
@@ -841,12 +840,12 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     float rr = 0.f;
     {
       const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
-      mg_up_smooth<false>(Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(PF_COARSE_GS);
     }
     for (int l = kc - 1; l >= 0; --l) {
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
-      mg_up_smooth<true>(F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
+      mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
       pf.mark(l == 0 ? PF_RR : PF_COARSE_GS);
     }
     if (P.exact_sums) rr = seq_inner(L0, sm);
@@ -862,8 +861,8 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
 // p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
 // shift; every reader of p (next solve's head, force, probes, field export) forms p+s itself --
 // the same float32 addition the reference's plusEq performs, so the bits are identical.
-template <bool HEUN>
-__device__ inline void project_tail_v2(const StepParams &P, const float *__restrict__ p, float shift, float *vx,
+__device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, const float *__restrict__ p, float shift,
+                                       float *vx,
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
                                        float *ax, float *ay) {
   const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
@@ -917,8 +916,9 @@ __device__ inline void project_tail_v2(const StepParams &P, const float *__restr
 
 // u.project(c, p) (VectorField.pde:130-143).  pin holds the previous pressure (+ pending shift),
 // the result is left in pout (a different buffer) with a new pending shift *shift_io.
-template <int C, bool HEUN>
-__device__ inline int project_v2(const StepParams &P, size_t e, float *vx, float *vy, const float *pin, float *pout,
+template <int C>
+__device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e, float *vx, float *vy,
+                                 const float *pin, float *pout,
                                  float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
                                  float *linf_out, Prof &pf, float *lds) {
   const size_t eo = e * (size_t)P.Ns;
@@ -930,7 +930,7 @@ __device__ inline int project_v2(const StepParams &P, size_t e, float *vx, float
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
   const float shift = -1 * psum / (float)((P.n - 2) * (P.m - 2));  // VectorField.pde:136
-  project_tail_v2<HEUN>(P, pout, shift, vx, vy, ox, oy, ax, ay);
+  project_tail_v2(HEUN, P, pout, shift, vx, vy, ox, oy, ax, ay);
   *shift_io = shift;
   pf.mark(PF_PROJECT);
   return iters;
@@ -949,23 +949,35 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   float shift = *pshift;
   Prof pf;
   pf.start(P);
-  // predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP
-  advdif_v2<C>(P, Ax, Ay, Ax, Ay, Bx, By, lds);
-  pf.mark(PF_ADVDIF);
-  forcing_band(P, Bx, By, scratch, dphi1, dphi2);
-  pf.mark(PF_FORCING);
-  setbc_vel(P, Bx, By);
-  pf.mark(PF_SETBC);
-  const int it0 = project_v2<C, false>(P, e, Bx, By, p0, p1, &shift, nullptr, nullptr, nullptr, nullptr, sm, &l0, pf,
-                                       lds);
-  // corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; u = (u+us)/2
-  advdif_v2<C>(P, Bx, By, Ax, Ay, Cx, Cy, lds);
-  pf.mark(PF_ADVDIF);
-  forcing_band(P, Cx, Cy, scratch, dphi1, dphi2);
-  pf.mark(PF_FORCING);
-  setbc_vel(P, Cx, Cy);
-  pf.mark(PF_SETBC);
-  const int it1 = project_v2<C, true>(P, e, Cx, Cy, p1, p0, &shift, Bx, By, Ax, Ay, sm, &l1, pf, lds);
+  // half 0 = predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP                    -> B
+  // half 1 = corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; (u+us)/2 -> C, A
+  int its[2] = {0, 0};
+  float lin[2] = {0.f, 0.f};
+#pragma nounroll
+  for (int half = 0; half < 2; ++half) {
+    const float *sx = half ? Bx : Ax, *sy = half ? By : Ay;
+    float *dx = half ? Cx : Bx, *dy = half ? Cy : By;
+    const float *pin = half ? p1 : p0;
+    float *pout = half ? p0 : p1;
+    advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+    pf.mark(PF_ADVDIF);
+    forcing_band(P, dx, dy, scratch, dphi1, dphi2);
+    pf.mark(PF_FORCING);
+    setbc_vel(P, dx, dy);
+    pf.mark(PF_SETBC);
+    float l;
+    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds);
+    if (half) {
+      its[1] = it;
+      lin[1] = l;
+    } else {
+      its[0] = it;
+      lin[0] = l;
+    }
+  }
+  const int it0 = its[0], it1 = its[1];
+  l0 = lin[0];
+  l1 = lin[1];
   *pshift = shift;
   if (threadIdx.x == 0) {
     float fx, fy;
