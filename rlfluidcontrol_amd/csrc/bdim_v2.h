@@ -681,15 +681,24 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
 // written once.  pin and pout are different buffers (rows a-2.. of pin are still needed when rows
 // ..a-1 of pout are written).
 // ---------------------------------------------------------------------------------------------
-__device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
-                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift,
-                                      float *lds) {
+// RESID = true : finest level, first iteration: r0 = div(u) - A (pin+s), x_out = (pin+s) + d
+// RESID = false: any level with an existing residual: r0 = F.r, x_out = F.x + d  (F.x is 0 on
+//                coarse levels, MG.pde:56; on the finest level it is the current iterate)
+template <bool RESID>
+__device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+                                     const float *__restrict__ uy, const float *__restrict__ pin, float shift,
+                                     float *lds) {
   const int n = L0.n, m = L0.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
   const LevelDesc &D = *L0.desc;
   float *pout = L0.x, *r = L0.r;
+  if (!RESID) {
+    pin = L0.x;
+    shift = 0.f;
+  }
   float *t0 = lds + 8;  // r0 tile: 16 rows, pitch m
   const int tid = threadIdx.x;
   const int m1 = L1.m;
+  const bool uni = (D.zero_bnd == 0);  // finest level: all coefficients uniform outside the special rows
   for (int q = tid; q < L1.n * L1.m; q += kThreads) L1.x[q] = 0.f;  // MG.pde:56
   const int R = 14;
   for (int a = 1; a <= n_; a += R) {
@@ -700,34 +709,40 @@ __device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const L
       const int t = q / CPR, c4 = q - t * CPR;
       const int g = a - 1 + t, j = 1 + 4 * c4;
       if (g < 1 || g > n_) continue;
+      if (!RESID && t == 0) continue;  // row a-1 was overwritten by the previous block: kept in the tile
       const int k = g * m + j;
-      const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
-      const float uyn = uy[k + 4];
-      const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
-      const float psl = pin[k - 1], pnr = pin[k + 4];
-      F4 lw, le, ls;
-      float ln4;
-      if (sp) {
-        lw = load4u(L0.lx + k);
-        le = load4u(L0.lx + k + m);
-        ls = load4u(L0.ly + k);
-        ln4 = L0.ly[k + 4];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
-        ln4 = D.cu;
-      }
       F4 r0;
+      if (RESID) {
+        const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
+        const float uyn = uy[k + 4];
+        const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
+        const float psl = pin[k - 1], pnr = pin[k + 4];
+        F4 lw, le, ls;
+        float ln4;
+        if (sp) {
+          lw = load4u(L0.lx + k);
+          le = load4u(L0.lx + k + m);
+          ls = load4u(L0.ly + k);
+          ln4 = L0.ly[k + 4];
+        } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
-        const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
-        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
-        const float diag = -(lwv + lev + lsv + lnv);
-        const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
-        const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift, pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
-        const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
-        r0.v[e] = div - ap;
+          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
+          ln4 = D.cu;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
+          const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
+          const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+          const float diag = -(lwv + lev + lsv + lnv);
+          const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
+          const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift,
+                      pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
+          const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
+          r0.v[e] = div - ap;
+        }
+      } else {
+        r0 = load4u(r + k);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) t0[t * m + j + e] = r0.v[e];
@@ -752,7 +767,7 @@ __device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const L
           float iv;
           if (sp) {
             iv = L0.inv[gg * m + jj];
-          } else if (!D.zero_bnd) {
+          } else if (uni) {
             iv = D.invtab[0];
           } else {
             iv = D.invtab[3 * ((gg == 1) ? 1 : ((gg == n_) ? 2 : 0)) + ((jj == 1) ? 1 : ((jj == m_) ? 2 : 0))];
@@ -771,10 +786,20 @@ __device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const L
           le = load4u(L0.lx + k + m);
           ls = load4u(L0.ly + k);
           ln4 = L0.ly[k + 4];
-        } else {
+        } else if (uni) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
           ln4 = D.cu;
+        } else {
+          float a0, a1, a2, a3, a4v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            coef_analytic(D, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
+            lw.v[e] = a0;
+            le.v[e] = a1;
+            ls.v[e] = a2;
+            if (e == 3) ln4 = a3;
+          }
         }
         const F4 pc = load4u(pin + k);
         const float *r0row = t0 + (gg - (a - 1)) * m + j;
@@ -812,6 +837,10 @@ __device__ inline void mg_down0_fused(const StepParams &P, const Lv &L0, const L
       L1.r[ci * m1 + cj] = rn[0][0] + rn[0][1] + rn[1][0] + rn[1][1];
       L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
     }
+    if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row 14) must keep its ORIGINAL r
+      __syncthreads();
+      for (int q = tid; q < m; q += kThreads) t0[q] = t0[14 * m + q];
+    }
   }
   __syncthreads();
 }
@@ -829,7 +858,9 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
       if (l == 0 && iter == 1 && fused_head) {
-        mg_down0_fused(P, L0, Cc, ux, uy, pin, shift, lds);
+        mg_down_fused<true>(P, L0, Cc, ux, uy, pin, shift, lds);
+      } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
+        mg_down_fused<false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
       } else {
         mg_dinv(F);  // smooth(0)
         mg_increment(F);
