@@ -129,8 +129,10 @@ def main():
             dist.all_gather_into_tensor(gathered, packed)
         g.reset(done.data_ptr())  # restart finished episodes (mask on device)
 
+    warm_sum = torch.zeros((), dtype=torch.int64, device=dev)
     for _ in range(args.warmup):
         agent_step()
+        warm_sum += nst.sum()  # same torch ops as the timed loop (their first call loads a code object)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -73,6 +73,20 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
         const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
         float fSx = 0.f, fSy = 0.f;
+        // the lane's C cells are contiguous: one (4-byte aligned) C-float load/store per array
+        const bool full = (j0 + C - 1 <= m - 2);
+        float bxv[C], byv[C], oxv[C], oyv[C];
+        if (full) {
+          __builtin_memcpy(bxv, bx + i * m + j0, sizeof(float) * C);
+          __builtin_memcpy(byv, by + i * m + j0, sizeof(float) * C);
+        } else {
+#pragma unroll
+          for (int e = 0; e < C; ++e) {
+            const bool in = (j0 + e <= m - 2);
+            bxv[e] = in ? bx[i * m + j0 + e] : 0.f;
+            byv[e] = in ? by[i * m + j0 + e] : 0.f;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < C; ++e) {
           const int j = j0 + e;
@@ -100,7 +114,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
             const float fN = vn * quick_face(TX(i, j - 1), xc, TX(i, j + 1), TX(i, j + 2), vn, rok && cok, rok && cokN);
             const float adv = ((fW - fE) + (fSx - fN));
             const float dif = TX(i + 1, j) + TX(i, j + 1) - 4 * xc + TX(i - 1, j) + TX(i, j - 1);  // :198-200
-            dx[i * m + j] = (adv + nu * dif) * dt + bx[i * m + j];                                  // :174
+            oxv[e] = (adv + nu * dif) * dt + bxv[e];  // :174
             fEx[e] = fE;
             fSx = fN;
           }
@@ -123,10 +137,21 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
             const float fN = vn * quick_face(TY(i, j - 1), yc, TY(i, j + 1), TY(i, j + 2), vn, rok && cok, rok && cokN);
             const float adv = ((fW - fE) + (fSy - fN));
             const float dif = TY(i + 1, j) + TY(i, j + 1) - 4 * yc + TY(i - 1, j) + TY(i, j - 1);
-            dy[i * m + j] = (adv + nu * dif) * dt + by[i * m + j];  // :175
+            oyv[e] = (adv + nu * dif) * dt + byv[e];  // :175
             fEy[e] = fE;
             fSy = fN;
           }
+        }
+        if (full) {
+          __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
+          __builtin_memcpy(dy + i * m + j0, oyv, sizeof(float) * C);
+        } else {
+#pragma unroll
+          for (int e = 0; e < C; ++e)
+            if (j0 + e <= m - 2) {
+              dx[i * m + j0 + e] = oxv[e];
+              dy[i * m + j0 + e] = oyv[e];
+            }
         }
       }
     }

@@ -179,7 +179,7 @@ def test_envs_are_independent(envmod, oracle_mod):
 
 
 @pytest.mark.parametrize("impl", [0, 2])
-@pytest.mark.parametrize("res,Re,init", [(8, 100, False), (16, 100, False), (24, 500, True)])
+@pytest.mark.parametrize("res,Re,init", [(8, 100, False), (16, 100, False), (24, 500, True), (32, 400, False)])
 def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init, impl):
     """cfg.exact_sums=1: every float the step produces equals the oracle's, bit for bit."""
     acts = [(0, 0)] * 3 + [(5.0, -5.0)] * 5 + [(-2.5, 1.0)] * 4 + [(0, 0)] * 4
