@@ -197,6 +197,16 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * cells * sim_per_launch,
                          "frac_of_measured_copy_ceiling_6.29TBs": round(achieved / 6.29e12, 5)},
         }
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be
+        # driven from inside this process); only valid for the exact workload they were taken on
+        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+        if os.path.exists(tpath) and (args.res, args.reynolds, E) == (16, 100, 1024):
+            try:
+                tj = json.load(open(tpath))
+                line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except Exception:
+                pass
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
