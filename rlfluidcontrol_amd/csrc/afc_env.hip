@@ -94,7 +94,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
   if (P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
-    const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> P.stagger_shift) & 3);
+    const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
   }
   EnvScalars s = P.sc[e];  // every thread keeps an identical private copy (uniform control flow)
@@ -432,12 +432,12 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.exact_sums = cfg->exact_sums;
   P.impl = cfg->impl;
   P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
-  P.stagger_shift = (cfg->stagger_us >> 20) & 15;  // experimental: which block-index bits pick the phase
+  P.stagger_shift = (cfg->stagger_us >> 20) & 63;  // experimental: bits 0-3 = block-index shift, bits 4-5 = phases-2
   P.adv_rows = (sf.m <= 130) ? 16 : 8;
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
     const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 2;  // advdif_v2
-    const size_t rings = 32 + (size_t)(2 * afc::kRing + 4) * sf.m + 32 + 64;  // mg_up_smooth (gs_lds_floats)
+    const size_t rings = (size_t)afc::gs_lds_floats(sf.m) + 64;  // mg_up_smooth
     env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * (tile > rings ? tile : rings);
   }
 

@@ -275,8 +275,8 @@ __device__ inline void phase_forcing(const StepParams &P, size_t eo, float dphi1
 // the last bits, and because the Neumann pressure problem is singular that flux rounding
 // shows up as a 1e-4 low-mode drift of p within a few steps.
 constexpr int kRowCap = 1024;
-__device__ inline void setbc_vel(const StepParams &P, float *ux, float *uy) {
-  __shared__ float rowbuf[kRowCap];
+__device__ inline void setbc_vel(const StepParams &P, float *ux, float *uy, float *rowbuf) {
+  // rowbuf: kRowCap floats of LDS scratch supplied by the caller
   __shared__ float s_mean;
   const int n = P.n, m = P.m;
   for (int j = threadIdx.x; j < m; j += kThreads) {
@@ -315,7 +315,8 @@ __device__ inline void setbc_vel(const StepParams &P, float *ux, float *uy) {
 }
 __device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
   (void)sm;
-  setbc_vel(P, P.ux + eo, P.uy + eo);
+  __shared__ float rowbuf_v1[kRowCap];
+  setbc_vel(P, P.ux + eo, P.uy + eo, rowbuf_v1);
 }
 
 // ---- multigrid (MG.pde, PoissonMatrix.pde) ----
@@ -567,7 +568,8 @@ __device__ inline int project_vel(const StepParams &P, size_t e, float *ux, floa
     }
   }
   __syncthreads();
-  setbc_vel(P, ux, uy);
+  __shared__ float rowbuf_v1p[kRowCap];
+  setbc_vel(P, ux, uy, rowbuf_v1p);
   pf.mark(PF_PROJECT);
   return iters;
 }

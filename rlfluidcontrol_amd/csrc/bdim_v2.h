@@ -242,8 +242,11 @@ __device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byt
 }
 __device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
 
-// LDS layout used by the smoother (floats): [pad 32][r ring 24*m][d ring 24*m][carry 4*m][pad 32][dummy 64]
-__device__ __forceinline__ int gs_lds_floats(int m) { return 32 + (2 * kRing + 4) * m + 32 + 64; }
+// LDS layout used by the smoother (floats, PW = m + kPad):
+//   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][carry 4*PW][kPad][zero row PW][kPad][dummy row PW]
+__device__ __host__ __forceinline__ int gs_lds_floats(int m) {
+  return 28 /*kPad*/ + (2 * 24 /*kRing*/ + 4 + 2) * (m + 28) + 4 * 28;
+}
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
 __device__ __forceinline__ void coef_analytic(const LevelDesc &D, int i, int j, int n_, int m_, float &lw, float &le,
@@ -261,58 +264,57 @@ __device__ __forceinline__ void coef_analytic(const LevelDesc &D, int i, int j, 
   iv = D.invtab[3 * ((i == 1) ? 1 : ((i == n_) ? 2 : 0)) + ((j == 1) ? 1 : ((j == m_) ? 2 : 0))];
 }
 
+// Ring rows are stored with pitch PW = m + kPad; the kPad trailing floats (and a kPad front pad of
+// each array) only ever receive zeros.  Running pointers are never clamped: a lane that is before
+// the first / past the last column of its row reads a pad, a lane whose row lies outside the grid
+// reads the all-zero row `zrow` and writes to `dummy`.  One unsigned compare per step forces the
+// result of such a lane to 0 (which is also what its neighbours must see: ghost d = 0); its writes
+// are unconditional -- zeros into a pad or the dummy row.
+constexpr int kPad = 28;
+
 template <bool FAST>
-__device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr, float *carry, float *dummy,
-                                         int I0) {
-  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
+__device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr, float *carry, float *zrow,
+                                         float *dummy, int I0) {
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = m + kPad;
   const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
   const int i = I0 - k + c;
   const bool row_ok = (i >= 1) && (i <= n_);
   const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);  // clamped for addressing only
-  const int slot = (ic % kRing) * m, slotE = ((ic + 1) % kRing) * m;
+  const int slot = (ic % kRing) * PW, slotE = ((ic + 1) % kRing) * PW;
   const LevelDesc &D = *L.desc;
-  float lwU = D.cu, leU = D.cu, iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
-  if (FAST) {  // row-dependent parts of the analytic coefficients
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
+  if (FAST) {  // row-dependent part of the analytic inverse diagonal
     const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
-    if (D.zero_bnd && i == 1) lwU = 0.f;
-    if (D.zero_bnd && i == n_) leU = 0.f;
     iv0 = D.invtab[3 * rc + 0];
     iv1 = D.invtab[3 * rc + 1];
     iv2 = D.invtab[3 * rc + 2];
   }
   const float cu = D.cu;
   const bool zb = D.zero_bnd != 0;
-  (void)lwU;
-  (void)leU;
   const int steps = (m_ + 18 + 3) & ~3;  // multiple of 4 (the extra steps are inactive)
-  // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k); nothing is
-  // clamped -- before/after its row a lane reads whatever lies beside it in LDS and discards it.
-  // Operands of step tau+1 are fetched during step tau, BEFORE that step's LDS writes: none of
-  // them can be written in between (carry rows are re-written >= 14 steps after their last read,
-  // d0 is overwritten by sweep 3 six columns behind sweep 0).  On strips that touch the bodies the
-  // five coefficients come from memory, four columns per 4-byte-aligned 16-byte load, one chunk
-  // ahead.  Writes of inactive lanes are steered to a dummy word.
+  const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
+  // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k).  Operands of
+  // a 4-step chunk are fetched at the end of the previous chunk, i.e. <= 4 steps early: carry rows
+  // are re-written >= 14 steps after their last read and d0 is overwritten by sweep 3 six columns
+  // behind sweep 0, so nothing fetched early can change in between.  On strips that touch the
+  // bodies the five coefficients come from memory, four columns per 4-byte-aligned 16-byte load, one
+  // chunk ahead.
   const int jo = 1 - c - k;
-  const float *p_rv = rr + slot + jo;
-  const float *p_cW = carry + k * m + jo;
-  const float *p_cN = carry + ((k + 3) & 3) * m + 1 + jo;
-  const float *p_dE = dr + slotE + jo;
-  const float *p_dN = dr + slot + 1 + jo;
-  float *w_d = dr + slot + jo;
-  float *w_c = carry + k * m + jo;
-  const bool wd_lane = row_ok && (k == 3);
-  const bool wc_lane = (c == 15);
-  float *const dmy = dummy + lane;
-  // LDS operands of the four steps of a chunk are fetched at the end of the previous chunk
-  // (<= 4 steps early: far inside the hazard margins above)
-  float o_rv[4], o_cW[4], o_cN[4], o_dE[4], o_dN[4];
+  const float *p_rv = (row_ok ? rr + slot : zrow) + jo;
+  // lanes c == 0 take d[i-1][j] (sweep k) and d[i][j+1] (sweep k-1) from the carry rows; sweep 0
+  // takes d0[i][j+1] through the same register (DPP keeps `old` where no lane feeds it)
+  const float *p_cW = carry + k * PW + jo;
+  const float *p_cN = (k == 0) ? ((row_ok ? dr + slot : zrow) + 1 + jo) : (carry + (k - 1) * PW + 1 + jo);
+  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;
+  float *w_d = ((row_ok && k == 3) ? dr + slot : dummy) + jo;
+  float *w_c = ((c == 15) ? carry + k * PW : dummy) + jo;
+  float o_rv[4], o_cW[4], o_cN[4], o_dE[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     o_rv[e] = p_rv[e];
     o_cW[e] = p_cW[e];
     o_cN[e] = p_cN[e];
     o_dE[e] = p_dE[e];
-    o_dN[e] = p_dN[e];
   }
   F4 c_lw, c_le, c_ls, c_iv, x_lw, x_le, x_ls, x_iv;
   float c_ln4 = 0.f, x_ln4 = 0.f;
@@ -338,25 +340,20 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       c_ln4 = x_ln4;
       GS_CHUNK(tau0 + 4, x_lw, x_le, x_ls, x_iv, x_ln4)
     }
-    const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4,
-                *q_dN = p_dN + tau0 + 4;
     float *qw_d = w_d + tau0, *qw_c = w_c + tau0;
     const int jb = tau0 + jo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = jb + e;
-      const bool col_ok = (j >= 1) && (j <= m_);
-      const bool act = row_ok && col_ok;
-      const float rv = o_rv[e], cW = o_cW[e], cN = o_cN[e], dE0 = o_dE[e], dN0 = o_dN[e];
       float lw, le, ls, ln, iv;
       if (FAST) {
         // every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform
         // coefficient: cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).
-        lw = cu;
-        le = cu;
-        ls = cu;
-        ln = cu;
-        iv = zb ? ((j == 1) ? iv1 : ((j == m_) ? iv2 : iv0)) : iv0;
+        lw = le = ls = ln = cu;
+        iv = iv0;
+        if (zb) {
+          const int j = jb + e;
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);
+        }
       } else {
         lw = c_lw.v[e];
         le = c_le.v[e];
@@ -365,25 +362,25 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
         iv = c_iv.v[e];
       }
       const float prev = res;
-      const float up16 = lane_minus16(prev, lane);  // (k-1, c): sweep k-1 at (i+1, j)
-      const float dW = dpp_row_shr1(cW, prev);      // (k, c-1): sweep k   at (i-1, j)
-      const float dNp = dpp_row_shr1(cN, up16);     // (k-1, c-1): sweep k-1 at (i, j+1)
-      const float dE = (k == 0) ? dE0 : up16;
-      const float dN = (k == 0) ? dN0 : dNp;
-      const float v = -(dW * lw + dE * le + prev * ls + dN * ln - rv) * iv;  // MG.pde:84-88
-      res = act ? v : 0.f;
-      float *a_d = (wd_lane && col_ok) ? (qw_d + e) : dmy;
-      float *a_c = (wc_lane && col_ok) ? (qw_c + e) : dmy;
-      *a_d = res;
-      *a_c = res;
+      const float up16 = lane_minus16(prev, lane);        // (k-1, c): sweep k-1 at (i+1, j)
+      const float dW = dpp_row_shr1(o_cW[e], prev);       // (k, c-1): sweep k at (i-1, j); c == 0: carry
+      // (k-1, c-1): sweep k-1 at (i, j+1); c == 0: carry; sweep 0 (DPP row 0 disabled): d0[i][j+1]
+      const float dN = __builtin_bit_cast(
+          float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, o_cN[e]), __builtin_bit_cast(int, up16), 0x111,
+                                             0xE, 0xF, false));
+      const float dE = (k == 0) ? o_dE[e] : up16;
+      const float v = -(dW * lw + dE * le + prev * ls + dN * ln - o_rv[e]) * iv;  // MG.pde:84-88
+      res = ((unsigned)(jb + e - 1) < m_eff) ? v : 0.f;
+      qw_d[e] = res;
+      qw_c[e] = res;
     }
+    const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {  // operands of the next chunk (issued after this chunk's LDS writes)
       o_rv[e] = q_rv[e];
       o_cW[e] = q_cW[e];
       o_cN[e] = q_cN[e];
       o_dE[e] = q_dE[e];
-      o_dN[e] = q_dN[e];
     }
   }
 #undef GS_CHUNK
@@ -404,7 +401,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
                                     float *rr_out,
                                     float *linf_out, Prof &pf, float *xsum_out = nullptr) {
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
-  float *rr = lds + 32, *dr = rr + kRing * m, *carry = dr + kRing * m, *dummy = carry + 4 * m + 32;
+  const int PW = m + kPad;
+  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
+        *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
@@ -415,7 +414,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const int CPR = m_ >> 2;
   const bool chunked = ((m_ & 3) == 0);
   __syncthreads();
-  for (int q = tid; q < 4 * m + 32; q += kThreads) carry[q] = 0.f;
+  // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
+  for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
+  __syncthreads();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
   for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
     // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
@@ -427,7 +428,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       for (int q = tid; q < nrow * CPR; q += kThreads) {
         const int t = q / CPR, c4 = q - t * CPR;
         const int g = loaded + 1 + t, j = 1 + 4 * c4;
-        const int sl = (g % kRing) * m + j;
+        const int sl = (g % kRing) * PW + j;
         F4 rv, dv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rv.v[e] = dv.v[e] = 0.f;
@@ -508,7 +509,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
           }
           dv = rv * iv;  // MG.pde:80
         }
-        const int sl = (g % kRing) * m + j;
+        const int sl = (g % kRing) * PW + j;
         rr[sl] = rv;
         dr[sl] = dv;
         g += rstep;
@@ -525,9 +526,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (tid < 64) {
       const bool special = (I0 + 16 >= D.sp_i0) && (I0 - 3 <= D.sp_i1);
       if (special)
-        gs_march<false>(F, rr, dr, carry, dummy, I0);
+        gs_march<false>(F, rr, dr, carry, zrow, dummy, I0);
       else
-        gs_march<true>(F, rr, dr, carry, dummy, I0);
+        gs_march<true>(F, rr, dr, carry, zrow, dummy, I0);
     }
     __syncthreads();
     if (need_r) pf.mark(PF_GS0);
@@ -540,7 +541,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
         const int t = q / CPR, c4 = q - t * CPR;
         const int g = e0 + t, j = 1 + 4 * c4, kk = g * m + j;
         const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
-        const int sl = (g % kRing) * m + j;
+        const int sl = (g % kRing) * PW + j;
         const F4 x4 = load4u(F.x + kk);
         float dp[4] = {0.f, 0.f, 0.f, 0.f};
         if (HASC) {
@@ -558,7 +559,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
         if (c4 == CPR - 1) d6[5] = d6[4];
         F4 xn;
         if (need_r) {
-          const float *dwp = dr + (gw % kRing) * m + j, *dep = dr + (ge % kRing) * m + j;
+          const float *dwp = dr + (gw % kRing) * PW + j, *dep = dr + (ge % kRing) * PW + j;
           F4 lw, le, ls;
           float ln4;
           if (sp_exit) {
@@ -631,10 +632,10 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
           const int kk = g * m + j;
           const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
           const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
-          const int sl = (g % kRing) * m;
+          const int sl = (g % kRing) * PW;
           const float d = dr[sl + j];
           if (need_r) {
-            const float dW = dr[(gw % kRing) * m + j], dE = dr[(ge % kRing) * m + j];
+            const float dW = dr[(gw % kRing) * PW + j], dE = dr[(ge % kRing) * PW + j];
             const float dS = dr[sl + js], dN = dr[sl + jn];
             float lw, le, ls, ln, iv;
             if (sp_exit) {
@@ -917,8 +918,8 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
 // p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
 // shift; every reader of p (next solve's head, force, probes, field export) forms p+s itself --
 // the same float32 addition the reference's plusEq performs, so the bits are identical.
-__device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, const float *__restrict__ p, float shift,
-                                       float *vx,
+__device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, float *lds, const float *__restrict__ p,
+                                       float shift, float *vx,
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
                                        float *ax, float *ay) {
   const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
@@ -952,7 +953,7 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, con
     }
   }
   __syncthreads();
-  setbc_vel(P, vx, vy);
+  setbc_vel(P, vx, vy, lds);
   if (HEUN) {  // lines touched by setBC: rows 0,1,n-1 and columns 0,1,m-1
     for (int q = threadIdx.x; q < 3 * m + 3 * n; q += kThreads) {
       int k;
@@ -986,7 +987,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
   const float shift = -1 * psum / (float)((P.n - 2) * (P.m - 2));  // VectorField.pde:136
-  project_tail_v2(HEUN, P, pout, shift, vx, vy, ox, oy, ax, ay);
+  project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay);
   *shift_io = shift;
   pf.mark(PF_PROJECT);
   return iters;
@@ -1019,7 +1020,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     pf.mark(PF_ADVDIF);
     forcing_band(P, dx, dy, scratch, dphi1, dphi2);
     pf.mark(PF_FORCING);
-    setbc_vel(P, dx, dy);
+    setbc_vel(P, dx, dy, lds);
     pf.mark(PF_SETBC);
     float l;
     const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds);
