@@ -32,6 +32,7 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 using afc::EnvScalars;
+using afc::G;
 using afc::kThreads;
 using afc::StepParams;
 
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
-  float pshift = P.sc[e].p_shift;
+  float pshift = G(P.sc)[e].p_shift;
   step_dispatch<CPL>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
   if (threadIdx.x == 0) {
-    EnvScalars &s = P.sc[e];
+    EnvScalars &s = G(P.sc)[e];
     s.p_shift = pshift;
     s.xi1_m = a;
     s.xi2_m = b;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
   }
-  EnvScalars s = P.sc[e];  // every thread keeps an identical private copy (uniform control flow)
+  EnvScalars s = G(P.sc)[e];  // every thread keeps an identical private copy (uniform control flow)
   const float a1 = action[2 * e], a2 = action[2 * e + 1];
   s.xi1 = a1;  // clientCFD.pde:51-54
   s.xi2 = a2;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    P.sc[e] = s;
+    G(P.sc)[e] = s;
     obs[2 * e] = s.obs_cl;  // wire order is Cl then Cd (clientCFD.pde:120)
     obs[2 * e + 1] = s.obs_cd;
     const float aa1 = afc::jabs(a1), aa2 = afc::jabs(a2);
@@ -156,14 +157,14 @@ __global__ void k_reset(StepParams P, const uint8_t *__restrict__ mask, const fl
   if (mask && !mask[e]) return;
   const size_t eo = e * (size_t)P.Ns;
   for (int k = threadIdx.x; k < P.N; k += blockDim.x) {
-    P.ux[eo + k] = ru[k];
-    P.uy[eo + k] = rv[k];
-    P.p[eo + k] = rp[k];
-    P.u0x[eo + k] = 0.f;  // BDIM.pde:53
-    P.u0y[eo + k] = 0.f;
+    G(P.ux)[eo + k] = ru[k];
+    G(P.uy)[eo + k] = rv[k];
+    G(P.p)[eo + k] = rp[k];
+    G(P.u0x)[eo + k] = 0.f;  // BDIM.pde:53
+    G(P.u0y)[eo + k] = 0.f;
   }
   if (threadIdx.x == 0) {
-    EnvScalars s = P.sc[e];
+    EnvScalars s = G(P.sc)[e];
     const int cl = s.callLearn;
     const float cd = s.Cd, cll = s.Cl;
     s = EnvScalars{};
@@ -173,13 +174,13 @@ __global__ void k_reset(StepParams P, const uint8_t *__restrict__ mask, const fl
       s.Cd = cd;
       s.Cl = cll;
     }
-    P.sc[e] = s;
+    G(P.sc)[e] = s;
   }
 }
 
 __global__ void k_vorticity(StepParams P, int env_idx, float *__restrict__ out) {  // VectorField.pde:78-87
   const size_t eo = (size_t)env_idx * P.Ns;
-  const float *x = P.ux + eo, *y = P.uy + eo;
+  const float *x = G(P.ux) + eo, *y = G(P.uy) + eo;
   const int n = P.n, m = P.m;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.N; k += gridDim.x * blockDim.x) {
     const int i = k / m, j = k - i * m;
@@ -191,8 +192,8 @@ __global__ void k_vorticity(StepParams P, int env_idx, float *__restrict__ out) 
 
 __global__ void k_probes(StepParams P, const afc::SampleDev *__restrict__ ps, int num, float *__restrict__ out) {
   const int e = blockIdx.x;
-  const float *p = P.p + (size_t)e * P.Ns;
-  const float sh = P.sc[e].p_shift;  // pending mean shift of the last projection (bdim_v2.h)
+  const float *p = G(P.p) + (size_t)e * P.Ns;
+  const float sh = G(P.sc)[e].p_shift;  // pending mean shift of the last projection (bdim_v2.h)
   const int m = P.m;
   for (int q = threadIdx.x; q < num; q += blockDim.x) {
     const afc::SampleDev sd = ps[q];
@@ -215,15 +216,15 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
     return;
   }
   for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {  // F starts as a copy of u (VectorField.pde:171)
-    P.fx[k] = P.ux[k];
-    P.fy[k] = P.uy[k];
+    G(P.fx)[k] = G(P.ux)[k];
+    G(P.fy)[k] = G(P.uy)[k];
   }
   __syncthreads();
   const int m_ = P.m - 2;
-  if (m_ <= 64) afc::advdif_v2<1>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
-  else if (m_ <= 128) afc::advdif_v2<2>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
-  else if (m_ <= 192) afc::advdif_v2<3>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
-  else afc::advdif_v2<4>(P, P.ux, P.uy, P.u0x, P.u0y, P.fx, P.fy, lds_dyn);
+  if (m_ <= 64) afc::advdif_v2<1>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
+  else if (m_ <= 128) afc::advdif_v2<2>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
+  else if (m_ <= 192) afc::advdif_v2<3>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
+  else afc::advdif_v2<4>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
 }
 __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   __shared__ double sm[afc::kThreads];
@@ -236,14 +237,14 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iter
   const int n = P.n, m = P.m;
   for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {
     const int i = k / m, j = k - i * m;
-    float rv = P.fx[k];  // b.minus(A.times(x)): ghosts of A x are 0 -> r ghost = b ghost
+    float rv = G(P.fx)[k];  // b.minus(A.times(x)): ghosts of A x are 0 -> r ghost = b ghost
     if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
       const float lw = L0.lx[k], le = L0.lx[k + m], ls = L0.ly[k], ln = L0.ly[k + 1];
       const float diag = -(lw + le + ls + ln);
-      const float *p = P.p;
-      rv = P.fx[k] - (p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln);
+      const float *p = G(P.p);
+      rv = G(P.fx)[k] - (p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln);
     }
-    P.r[k] = rv;
+    G(P.r)[k] = rv;
   }
   __syncthreads();
   float l;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iter
     it = afc::mg_solve(P, 0, sm, &l, pf);
   } else {
     afc::Lv L0v = afc::make_level(P, 0, 0);
-    L0v.d = P.u0y;
+    L0v.d = G(P.u0y);
     float xs;
     it = afc::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
   }
@@ -311,6 +312,22 @@ int dev_upload(afc_env *env, const T **p, const std::vector<T> &h) {
   HIP_TRY(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   *p = q;
   return AFC_OK;
+}
+
+// StepParams members are address_space(1) pointers (see bdim_device.h): same allocations, typed
+template <typename T>
+int dev_alloc(afc_env *env, AFC_AS1 T **p, size_t count) {
+  T *q = nullptr;
+  int rc = dev_alloc(env, &q, count);
+  *p = (AFC_AS1 T *)q;
+  return rc;
+}
+template <typename T>
+int dev_upload(afc_env *env, const AFC_AS1 T **p, const std::vector<T> &h) {
+  const T *q = nullptr;
+  int rc = dev_upload(env, &q, h);
+  *p = (const AFC_AS1 T *)q;
+  return rc;
 }
 
 int check_env(const afc_env *env) {
@@ -509,15 +526,15 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_upload(env, &P.fs, fs);
 
   const size_t E = (size_t)env->E;
-  float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
-  for (float **f : fields) {
+  AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
+  for (AFC_AS1 float **f : fields) {
     if (!rc) rc = dev_alloc(env, f, E * P.Ns);
-    if (!rc && hipMemset(*f, 0, E * P.Ns * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+    if (!rc && hipMemset(G(*f), 0, E * P.Ns * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   }
   if (!rc) rc = dev_alloc(env, &P.coarse, E * (size_t)P.Cs);
-  if (!rc && hipMemset(P.coarse, 0, E * (size_t)P.Cs * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  if (!rc && hipMemset(G(P.coarse), 0, E * (size_t)P.Cs * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (!rc) rc = dev_alloc(env, &P.sc, E);
-  if (!rc && hipMemset(P.sc, 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  if (!rc && hipMemset(G(P.sc), 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (!rc) rc = dev_alloc(env, &env->rs_u, (size_t)P.Ns);
   if (!rc) rc = dev_alloc(env, &env->rs_v, (size_t)P.Ns);
   if (!rc) rc = dev_alloc(env, &env->rs_p, (size_t)P.Ns);
@@ -645,7 +662,7 @@ int afc_save_state_bdim(afc_env *env, int env_idx, const char *path) {  // BDIM.
   if (!rc) rc = afc_get_field(env, env_idx, AFC_FIELD_P, p.data());
   if (rc) return rc;
   EnvScalars s;
-  HIP_TRY(hipMemcpy(&s, env->P.sc + env_idx, sizeof(s), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&s, G(env->P.sc) + env_idx, sizeof(s), hipMemcpyDeviceToHost));
   FILE *f = fopen(path, "w");
   if (!f) return fail(AFC_EIO, std::string("afc_save_state_bdim: cannot open ") + path);
   // BDIM.t advances by dt per step (BDIM.pde:106); %.9g round-trips every float32
@@ -746,7 +763,7 @@ static int fetch_scalars(afc_env *env, std::vector<EnvScalars> &h) {
   HIP_TRY(hipSetDevice(env->cfg.device));
   HIP_TRY(hipStreamSynchronize(env->stream));
   h.resize(env->E);
-  HIP_TRY(hipMemcpy(h.data(), env->P.sc, env->E * sizeof(EnvScalars), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h.data(), G(env->P.sc), env->E * sizeof(EnvScalars), hipMemcpyDeviceToHost));
   return AFC_OK;
 }
 
@@ -793,11 +810,11 @@ int afc_get_field(afc_env *env, int env_idx, int which, float *out) {
   const size_t eo = (size_t)env_idx * P.Ns, bytes = (size_t)P.N * sizeof(float);
   const float *src = nullptr;
   switch (which) {
-    case AFC_FIELD_U: src = P.ux + eo; break;
-    case AFC_FIELD_V: src = P.uy + eo; break;
-    case AFC_FIELD_P: src = P.p + eo; break;
+    case AFC_FIELD_U: src = G(P.ux) + eo; break;
+    case AFC_FIELD_V: src = G(P.uy) + eo; break;
+    case AFC_FIELD_P: src = G(P.p) + eo; break;
     case AFC_FIELD_VORT: {
-      float *tmp = P.fx + eo;  // fx is scratch between steps
+      float *tmp = G(P.fx) + eo;  // fx is scratch between steps
       hipLaunchKernelGGL(k_vorticity, dim3(64), dim3(256), 0, env->stream, P, env_idx, tmp);
       int rc = launch_check("k_vorticity");
       if (rc) return rc;
@@ -810,7 +827,7 @@ int afc_get_field(afc_env *env, int env_idx, int which, float *out) {
   HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
   if (which == AFC_FIELD_P) {  // apply the pending mean shift (p.plusEq(-mean), VectorField.pde:136)
     EnvScalars s;
-    HIP_TRY(hipMemcpy(&s, P.sc + env_idx, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&s, G(P.sc) + env_idx, sizeof(s), hipMemcpyDeviceToHost));
     if (s.p_shift != 0.f)
       for (int k = 0; k < P.N; ++k) out[k] = out[k] + s.p_shift;
   }
@@ -825,15 +842,15 @@ int afc_set_field(afc_env *env, int env_idx, int which, const float *in) {
   const size_t eo = (size_t)env_idx * P.Ns;
   float *dst = nullptr;
   switch (which) {
-    case AFC_FIELD_U: dst = P.ux + eo; break;
-    case AFC_FIELD_V: dst = P.uy + eo; break;
-    case AFC_FIELD_P: dst = P.p + eo; break;
+    case AFC_FIELD_U: dst = G(P.ux) + eo; break;
+    case AFC_FIELD_V: dst = G(P.uy) + eo; break;
+    case AFC_FIELD_P: dst = G(P.p) + eo; break;
     default: return fail(AFC_EINVAL, "afc_set_field: field is read-only or unknown");
   }
   HIP_TRY(hipMemcpy(dst, in, (size_t)P.N * sizeof(float), hipMemcpyHostToDevice));
   if (which == AFC_FIELD_P) {
     const float zero = 0.f;
-    HIP_TRY(hipMemcpy(reinterpret_cast<char *>(P.sc + env_idx) + offsetof(EnvScalars, p_shift), &zero, sizeof(float),
+    HIP_TRY(hipMemcpy(reinterpret_cast<char *>(G(P.sc) + env_idx) + offsetof(EnvScalars, p_shift), &zero, sizeof(float),
                       hipMemcpyHostToDevice));
   }
   return AFC_OK;
@@ -908,7 +925,7 @@ int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count) 
     HIP_TRY(hipMemcpy(ticks_out, env->d_stamps, count * sizeof(long long), hipMemcpyDeviceToHost));
   }
   HIP_TRY(hipMemset(env->d_stamps, 0, 32 * sizeof(long long)));
-  env->P.stamps = enable ? env->d_stamps : nullptr;
+  env->P.stamps = (AFC_AS1 long long *)(enable ? env->d_stamps : nullptr);
   env->p_dirty = true;
   return AFC_OK;
 }
@@ -921,16 +938,16 @@ int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const fl
   HIP_TRY(hipStreamSynchronize(env->stream));
   const StepParams &P = env->P;
   const size_t bytes = (size_t)P.N * sizeof(float);
-  HIP_TRY(hipMemcpy(P.ux, fx, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(P.uy, fy, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(P.u0x, u0x, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(P.u0y, u0y, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.ux), fx, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.uy), fy, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.u0x), u0x, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.u0y), u0y, bytes, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_op_advdif, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
   int rc = launch_check("k_op_advdif");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
-  HIP_TRY(hipMemcpy(fx, P.fx, bytes, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(fy, P.fy, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fx, G(P.fx), bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fy, G(P.fy), bytes, hipMemcpyDeviceToHost));
   return AFC_OK;
 }
 
@@ -941,14 +958,14 @@ int afc_op_setbc_u(afc_env *env, float *ux, float *uy) {
   HIP_TRY(hipStreamSynchronize(env->stream));
   const StepParams &P = env->P;
   const size_t bytes = (size_t)P.N * sizeof(float);
-  HIP_TRY(hipMemcpy(P.ux, ux, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(P.uy, uy, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.ux), ux, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.uy), uy, bytes, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_op_setbc, dim3(1), dim3(kThreads), 0, env->stream, P);
   int rc = launch_check("k_op_setbc");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
-  HIP_TRY(hipMemcpy(ux, P.ux, bytes, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(uy, P.uy, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ux, G(P.ux), bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(uy, G(P.uy), bytes, hipMemcpyDeviceToHost));
   return AFC_OK;
 }
 
@@ -959,15 +976,15 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   HIP_TRY(hipStreamSynchronize(env->stream));
   const StepParams &P = env->P;
   const size_t bytes = (size_t)P.N * sizeof(float);
-  HIP_TRY(hipMemcpy(P.p, x, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(P.fx, b, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.p), x, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.fx), b, bytes, hipMemcpyHostToDevice));
   int *dit = reinterpret_cast<int *>(env->d_i32);
   float *dl = env->d_f1;
   hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
-  HIP_TRY(hipMemcpy(x, P.p, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(x, G(P.p), bytes, hipMemcpyDeviceToHost));
   int it = 0;
   float l = 0;
   HIP_TRY(hipMemcpy(&it, dit, sizeof(int), hipMemcpyDeviceToHost));

@@ -20,6 +20,19 @@ namespace afc {
 constexpr int kThreads = 256;    // workgroup size (4 waves)
 constexpr int kMaxLevels = 12;
 
+#define AFC_AS1 __attribute__((address_space(1)))
+// Global-memory pointers inside StepParams carry their address space: the struct itself is read
+// from device memory, so without it every access would be a flat_* instruction.  G() converts to an
+// ordinary pointer; the compiler still knows where it came from and emits global_* loads/stores.
+template <class T>
+__host__ __device__ __forceinline__ T *G(AFC_AS1 T *p) {
+  return (T *)p;
+}
+template <class T>
+__host__ __device__ __forceinline__ const T *G(const AFC_AS1 T *p) {
+  return (const T *)p;
+}
+
 struct LevelDesc {
   int n, m;          // array size incl. ghosts
   int coef_off;      // offset (floats) of this level in mg_lx/mg_ly/mg_inv
@@ -65,17 +78,17 @@ struct StepParams {
   float dt, nu, D, dR, mg_tol;
   int mg_max_iters, resolution;
   // env-shared static fields (L2/MALL resident)
-  const float *delx, *dely, *del1x, *del1y, *wnxx, *wnxy, *wnyx, *wnyy, *cx, *cy;
-  const float *w1x, *w2x, *ry1x, *ry2x, *w1y, *w2y, *rx1y, *rx2y;
-  const float *mg_lx, *mg_ly, *mg_inv;
-  const SampleDev *fs;
-  const float *seg_l, *seg_nx, *seg_ny;
+  const AFC_AS1 float *delx, *dely, *del1x, *del1y, *wnxx, *wnxy, *wnyx, *wnyy, *cx, *cy;
+  const AFC_AS1 float *w1x, *w2x, *ry1x, *ry2x, *w1y, *w2y, *rx1y, *rx2y;
+  const AFC_AS1 float *mg_lx, *mg_ly, *mg_inv;
+  const AFC_AS1 SampleDev *fs;
+  const AFC_AS1 float *seg_l, *seg_nx, *seg_ny;
   int nseg;
   // per-env state [E][Ns]
-  float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d;
-  float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
-  EnvScalars *sc;
-  long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
+  AFC_AS1 float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d;
+  AFC_AS1 float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
+  AFC_AS1 EnvScalars *sc;
+  AFC_AS1 long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
   // episode constants
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
@@ -84,7 +97,7 @@ struct StepParams {
   int stagger_ticks;   // start delay (100 MHz ticks) per workgroup phase: de-synchronises the envs of a CU
   int impl;            // 0 = v1 reference kernels, 2 = optimised kernels
   int adv_rows;        // rows per LDS tile block in advdif_v2
-  const int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
+  const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
 };
 
@@ -102,7 +115,7 @@ struct Prof {
   long long *acc;
   long long last;
   __device__ void start(const StepParams &P) {
-    acc = (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? P.stamps : nullptr;
+    acc = (G(P.stamps) && blockIdx.x == 0 && threadIdx.x == 0) ? G(P.stamps) : nullptr;
     if (acc) last = wall_clock64();
   }
   __device__ __forceinline__ void mark(int id) {
@@ -193,10 +206,10 @@ __device__ __forceinline__ float advdif_y(const float *__restrict__ x, const flo
 //           corrector (BDIM.update2, BDIM.pde:89-97): us = u; F = u; F.AdvDif(u0)
 __device__ inline void phase_advdif(const StepParams &P, size_t eo, bool corrector) {
   const int n = P.n, m = P.m;
-  const float *ux = P.ux + eo, *uy = P.uy + eo;
-  float *savx = (corrector ? P.usx : P.u0x) + eo, *savy = (corrector ? P.usy : P.u0y) + eo;
-  const float *u0x = P.u0x + eo, *u0y = P.u0y + eo;
-  float *fx = P.fx + eo, *fy = P.fy + eo;
+  const float *ux = G(P.ux) + eo, *uy = G(P.uy) + eo;
+  float *savx = (corrector ? G(P.usx) : G(P.u0x)) + eo, *savy = (corrector ? G(P.usy) : G(P.u0y)) + eo;
+  const float *u0x = G(P.u0x) + eo, *u0y = G(P.u0y) + eo;
+  float *fx = G(P.fx) + eo, *fy = G(P.fy) + eo;
   for (int k = threadIdx.x; k < P.N; k += kThreads) {
     const int i = k / m, j = k - i * m;
     const float cxv = ux[k], cyv = uy[k];
@@ -218,49 +231,49 @@ __device__ inline void phase_advdif(const StepParams &P, size_t eo, bool correct
 __device__ __forceinline__ float ub_x_at(const StepParams &P, int k, float dphi1, float dphi2) {
   float v = 0.f;
   v += 0.f;  // main cylinder: dphi == 0 -> (0 - ry*0)/dt * w0 == 0
-  v += ((0.f - P.ry1x[k] * dphi1) / P.dt) * P.w1x[k];
-  v += ((0.f - P.ry2x[k] * dphi2) / P.dt) * P.w2x[k];
+  v += ((0.f - G(P.ry1x)[k] * dphi1) / P.dt) * G(P.w1x)[k];
+  v += ((0.f - G(P.ry2x)[k] * dphi2) / P.dt) * G(P.w2x)[k];
   return v;
 }
 __device__ __forceinline__ float ub_y_at(const StepParams &P, int k, float dphi1, float dphi2) {
   float v = 0.f;
   v += 0.f;
-  v += ((0.f + P.rx1y[k] * dphi1) / P.dt) * P.w1y[k];
-  v += ((0.f + P.rx2y[k] * dphi2) / P.dt) * P.w2y[k];
+  v += ((0.f + G(P.rx1y)[k] * dphi1) / P.dt) * G(P.w1y)[k];
+  v += ((0.f + G(P.rx2y)[k] * dphi2) / P.dt) * G(P.w2y)[k];
   return v;
 }
 
 // Phase B.  BDIM.updateUP lines 118-120 (BDIM.pde): u = del*F - ub*(del-1) + del1*ddn(F-ub)
 __device__ inline void phase_forcing(const StepParams &P, size_t eo, float dphi1, float dphi2) {
   const int n = P.n, m = P.m;
-  const float *fx = P.fx + eo, *fy = P.fy + eo;
-  float *ux = P.ux + eo, *uy = P.uy + eo;
+  const float *fx = G(P.fx) + eo, *fy = G(P.fy) + eo;
+  float *ux = G(P.ux) + eo, *uy = G(P.uy) + eo;
   for (int k = threadIdx.x; k < P.N; k += kThreads) {
     const int i = k / m, j = k - i * m;
     const bool interior = (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2);
     {
-      const float del = P.delx[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
+      const float del = G(P.delx)[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
       float un = del * R - ub * (del + (-1.f));
       if (interior) {  // VectorField.normalGrad, VectorField.pde:46-54 (ghosts of g are 0)
         const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
         const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
         const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
         const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
-        const float g = 0.5f * (P.wnxx[k] * (dE - dW) + P.wnyx[k] * (dN - dS));
-        un = un + P.del1x[k] * g;
+        const float g = 0.5f * (G(P.wnxx)[k] * (dE - dW) + G(P.wnyx)[k] * (dN - dS));
+        un = un + G(P.del1x)[k] * g;
       }
       ux[k] = un;
     }
     {
-      const float del = P.dely[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
+      const float del = G(P.dely)[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
       float un = del * R - ub * (del + (-1.f));
       if (interior) {
         const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
         const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
         const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
         const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
-        const float g = 0.5f * (P.wnxy[k] * (dE - dW) + P.wnyy[k] * (dN - dS));
-        un = un + P.del1y[k] * g;
+        const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
+        un = un + G(P.del1y)[k] * g;
       }
       uy[k] = un;
     }
@@ -316,7 +329,7 @@ __device__ inline void setbc_vel(const StepParams &P, float *ux, float *uy, floa
 __device__ inline void phase_setbc_u(const StepParams &P, size_t eo, double *sm) {
   (void)sm;
   __shared__ float rowbuf_v1[kRowCap];
-  setbc_vel(P, P.ux + eo, P.uy + eo, rowbuf_v1);
+  setbc_vel(P, G(P.ux) + eo, G(P.uy) + eo, rowbuf_v1);
 }
 
 // ---- multigrid (MG.pde, PoissonMatrix.pde) ----
@@ -331,18 +344,18 @@ __device__ __forceinline__ Lv make_level(const StepParams &P, size_t e, int l) {
   Lv L;
   L.n = P.lev[l].n;
   L.m = P.lev[l].m;
-  L.lx = P.mg_lx + P.lev[l].coef_off;
-  L.ly = P.mg_ly + P.lev[l].coef_off;
-  L.inv = P.mg_inv + P.lev[l].coef_off;
+  L.lx = G(P.mg_lx) + P.lev[l].coef_off;
+  L.ly = G(P.mg_ly) + P.lev[l].coef_off;
+  L.inv = G(P.mg_inv) + P.lev[l].coef_off;
   L.desc = &P.lev[l];
   if (l == 0) {
     const size_t eo = e * (size_t)P.Ns;
-    L.r = P.r + eo;
-    L.x = P.p + eo;
-    L.d = P.d + eo;
+    L.r = G(P.r) + eo;
+    L.x = G(P.p) + eo;
+    L.d = G(P.d) + eo;
   } else {
     const int q = P.Cs / 4;
-    float *base = P.coarse + e * (size_t)P.Cs + P.lev[l].scratch_off;
+    float *base = G(P.coarse) + e * (size_t)P.Cs + P.lev[l].scratch_off;
     L.r = base;
     L.x = base + q;
     L.d = base + 2 * q;
@@ -527,7 +540,7 @@ __device__ inline int project_vel(const StepParams &P, size_t e, float *ux, floa
                                   Prof &pf, float *lds = nullptr) {
   const int n = P.n, m = P.m;
   const size_t eo = e * (size_t)P.Ns;
-  float *p = P.p + eo, *r = P.r + eo;
+  float *p = G(P.p) + eo, *r = G(P.r) + eo;
   const Lv L0 = make_level(P, e, 0);
   // r = b - A x with b = divergence (VectorField.pde:56-65, MG.pde:51)
   for (int k = threadIdx.x; k < P.N; k += kThreads) {
@@ -563,8 +576,8 @@ __device__ inline int project_vel(const StepParams &P, size_t e, float *ux, floa
     if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
       const float pc = p[k];
       const float gx = pc - p[k - m], gy = pc - p[k - 1];
-      ux[k] = ux[k] + P.cx[k] * (gx * -1.f);
-      uy[k] = uy[k] + P.cy[k] * (gy * -1.f);
+      ux[k] = ux[k] + G(P.cx)[k] * (gx * -1.f);
+      uy[k] = uy[k] + G(P.cy)[k] * (gy * -1.f);
     }
   }
   __syncthreads();
@@ -575,7 +588,7 @@ __device__ inline int project_vel(const StepParams &P, size_t e, float *ux, floa
 }
 __device__ inline int phase_project(const StepParams &P, size_t e, double *sm, float *linf_out, Prof &pf) {
   const size_t eo = e * (size_t)P.Ns;
-  return project_vel(P, e, P.ux + eo, P.uy + eo, sm, linf_out, pf);
+  return project_vel(P, e, G(P.ux) + eo, G(P.uy) + eo, sm, linf_out, pf);
 }
 
 // Body.pressForce(flow.p).mult(-1) of the main cylinder (Body.pde:296-303, AFCCylinder.pde:58)
@@ -583,7 +596,7 @@ __device__ inline void eval_force(const StepParams &P, const float *p, float shi
   float px = 0, py = 0;
   const int m = P.m;
   for (int s = 0; s < P.nseg; ++s) {
-    const SampleDev sd = P.fs[s];
+    const SampleDev sd = G(P.fs)[s];
     const float *a = p + sd.base;
     float val;
     if (sd.exact) {
@@ -592,9 +605,9 @@ __device__ inline void eval_force(const StepParams &P, const float *p, float shi
       val = sd.s * (sd.t * (a[m + 1] + shift) + (1 - sd.t) * (a[m] + shift)) +
             (1 - sd.s) * (sd.t * (a[1] + shift) + (1 - sd.t) * (a[0] + shift));
     }
-    const float pdl = val * P.seg_l[s];
-    px += pdl * P.seg_nx[s];
-    py += pdl * P.seg_ny[s];
+    const float pdl = val * G(P.seg_l)[s];
+    px += pdl * G(P.seg_nx)[s];
+    py += pdl * G(P.seg_ny)[s];
   }
   *fxo = px * -1.f;
   *fyo = py * -1.f;
@@ -632,8 +645,8 @@ __device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, floa
   pf.mark(PF_SETBC);
   const int it1 = phase_project(P, e, sm, &l1, pf);
   {  // u = (u + us) * 0.5 on the whole array, no setBC (BDIM.pde:95-96)
-    float *ux = P.ux + eo, *uy = P.uy + eo;
-    const float *usx = P.usx + eo, *usy = P.usy + eo;
+    float *ux = G(P.ux) + eo, *uy = G(P.uy) + eo;
+    const float *usx = G(P.usx) + eo, *usy = G(P.usy) + eo;
     for (int k = threadIdx.x; k < P.N; k += kThreads) {
       ux[k] = (ux[k] + usx[k]) * 0.5f;
       uy[k] = (uy[k] + usy[k]) * 0.5f;
@@ -641,7 +654,7 @@ __device__ inline void sim_step(const StepParams &P, size_t e, float xi1_m, floa
   }
   if (threadIdx.x == 0) {
     float fx, fy;
-    eval_force(P, P.p + eo, 0.f, &fx, &fy);
+    eval_force(P, G(P.p) + eo, 0.f, &fx, &fy);
     sh->fx = fx;
     sh->fy = fy;
     sh->it0 = it0;

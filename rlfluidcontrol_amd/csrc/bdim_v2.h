@@ -169,32 +169,32 @@ __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, f
                                     float dphi2) {
   const int m = P.m;
   for (int q = threadIdx.x; q < P.nband_x; q += kThreads) {
-    const int k = P.band_x[q];
-    const float del = P.delx[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
+    const int k = G(P.band_x)[q];
+    const float del = G(P.delx)[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
     float un = del * R - ub * (del + (-1.f));
     const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
     const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
     const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
     const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
-    const float g = 0.5f * (P.wnxx[k] * (dE - dW) + P.wnyx[k] * (dN - dS));
-    un = un + P.del1x[k] * g;
+    const float g = 0.5f * (G(P.wnxx)[k] * (dE - dW) + G(P.wnyx)[k] * (dN - dS));
+    un = un + G(P.del1x)[k] * g;
     scratch[q] = un;
   }
   for (int q = threadIdx.x; q < P.nband_y; q += kThreads) {
-    const int k = P.band_y[q];
-    const float del = P.dely[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
+    const int k = G(P.band_y)[q];
+    const float del = G(P.dely)[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
     float un = del * R - ub * (del + (-1.f));
     const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
     const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
     const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
     const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
-    const float g = 0.5f * (P.wnxy[k] * (dE - dW) + P.wnyy[k] * (dN - dS));
-    un = un + P.del1y[k] * g;
+    const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
+    un = un + G(P.del1y)[k] * g;
     scratch[P.nband_x + q] = un;
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) fx[P.band_x[q]] = scratch[q];
-  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) fy[P.band_y[q]] = scratch[P.nband_x + q];
+  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) fx[G(P.band_x)[q]] = scratch[q];
+  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) fy[G(P.band_y)[q]] = scratch[P.nband_x + q];
   __syncthreads();
 }
 
@@ -928,7 +928,7 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
     const int k = g * m + 1 + 4 * c4;
     const F4 pc = load4u(p + k), pw = load4u(p + k - m);
     const float psl = p[k - 1];
-    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k), cx4 = load4u(P.cx + k), cy4 = load4u(P.cy + k);
+    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k), cx4 = load4u(G(P.cx) + k), cy4 = load4u(G(P.cy) + k);
     F4 un, vn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -981,7 +981,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   const size_t eo = e * (size_t)P.Ns;
   Lv L0 = make_level(P, e, 0);
   L0.x = pout;
-  L0.d = P.u0y + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
+  L0.d = G(P.u0y) + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
   float xsum = 0.f;
   const int iters = mg_solve_v2(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
   float psum = xsum;
@@ -999,9 +999,9 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
   const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
-  float *Ax = P.ux + eo, *Ay = P.uy + eo, *Bx = P.usx + eo, *By = P.usy + eo, *Cx = P.fx + eo, *Cy = P.fy + eo;
-  float *scratch = P.u0x + eo;
-  float *p0 = P.p + eo, *p1 = P.d + eo;  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
+  float *Ax = G(P.ux) + eo, *Ay = G(P.uy) + eo, *Bx = G(P.usx) + eo, *By = G(P.usy) + eo, *Cx = G(P.fx) + eo, *Cy = G(P.fy) + eo;
+  float *scratch = G(P.u0x) + eo;
+  float *p0 = G(P.p) + eo, *p1 = G(P.d) + eo;  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
   float shift = *pshift;
   Prof pf;
