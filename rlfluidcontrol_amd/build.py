@@ -34,11 +34,22 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    # several ranks of one node may get here together (torchrun): serialise, re-check, build to a
+    # temporary name and rename so that nobody ever loads a half-written library
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                tmp = LIB + ".tmp.%d" % os.getpid()
+                cmd = [hipcc] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB
 
 
