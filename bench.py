@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--reynolds", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-us", type=int, default=0)
+    ap.add_argument("--dbg", type=int, default=0, help="experiment switches (development only)")
     ap.add_argument("--init", default=os.path.join(ROOT, "tests", "golden", "wake_res16_re100.npz"),
                     help="developed-wake state to start from (falls back to the free stream)")
     args = ap.parse_args()
@@ -99,7 +100,7 @@ def main():
     build.build()
     E = args.envs
     g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank,
-                      stagger_us=args.stagger_us)
+                      stagger_us=args.stagger_us, dbg=args.dbg)
     init_used = "free stream"
     if args.init and os.path.exists(args.init):
         z = np.load(args.init)

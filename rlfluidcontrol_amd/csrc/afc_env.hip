@@ -448,6 +448,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.carry_quirk = cfg->carry_quirk;
   P.exact_sums = cfg->exact_sums;
   P.impl = cfg->impl;
+  P.dbg = cfg->reserved[0];
   P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
   P.stagger_shift = (cfg->stagger_us >> 20) & 63;  // experimental: bits 0-3 = block-index shift, bits 4-5 = phases-2
   P.adv_rows = (sf.m <= 130) ? 16 : 8;

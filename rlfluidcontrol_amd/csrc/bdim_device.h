@@ -93,6 +93,7 @@ struct StepParams {
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
   // v2 path
+  int dbg;             // experiment switches (bit flags), 0 in production
   int stagger_shift;
   int stagger_ticks;   // start delay (100 MHz ticks) per workgroup phase: de-synchronises the envs of a CU
   int impl;            // 0 = v1 reference kernels, 2 = optimised kernels

@@ -415,6 +415,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const bool chunked = ((m_ & 3) == 0);
   __syncthreads();
   // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
+  // (the region is shared with the other phases' tiles, so this is redone on every call)
   for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
   __syncthreads();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
@@ -726,12 +727,20 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   const int m1 = L1.m;
   const bool uni = (D.zero_bnd == 0);  // finest level: all coefficients uniform outside the special rows
   for (int q = tid; q < L1.n * L1.m; q += kThreads) L1.x[q] = 0.f;  // MG.pde:56
-  const int R = 14;
+  // rows per block: 14 on the finest grids; on narrow (coarse) levels enough rows to give every
+  // thread a patch (7*k*CPR patches per block), bounded by the 2080-float tile
+  int kblk = 1;
+  if (!RESID && !(P.dbg & 1)) {
+    kblk = 32 / (CPR > 0 ? CPR : 1);
+    if (kblk < 1) kblk = 1;
+    while (kblk > 1 && (14 * kblk + 2) * m > 2080) --kblk;
+  }
+  const int R = 14 * kblk, TR = R + 2, NPAIR = 7 * kblk;
   for (int a = 1; a <= n_; a += R) {
     const bool sp = (a + R + 1 >= D.sp_i0) && (a - 2 <= D.sp_i1);
     __syncthreads();
-    // ---- step 1: r0 for rows a-1 .. a+14 ----
-    for (int q = tid; q < 16 * CPR; q += kThreads) {
+    // ---- step 1: r0 for rows a-1 .. a+R ----
+    for (int q = tid; q < TR * CPR; q += kThreads) {
       const int t = q / CPR, c4 = q - t * CPR;
       const int g = a - 1 + t, j = 1 + 4 * c4;
       if (g < 1 || g > n_) continue;
@@ -775,7 +784,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
     }
     __syncthreads();
     // ---- step 2: one 2x4 patch per thread ----
-    for (int q = tid; q < 7 * CPR; q += kThreads) {
+    for (int q = tid; q < NPAIR * CPR; q += kThreads) {
       const int pr = q / CPR, c4 = q - pr * CPR;
       const int g = a + 2 * pr, j = 1 + 4 * c4;
       if (g > n_) continue;
@@ -865,7 +874,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
     }
     if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row 14) must keep its ORIGINAL r
       __syncthreads();
-      for (int q = tid; q < m; q += kThreads) t0[q] = t0[14 * m + q];
+      for (int q = tid; q < m; q += kThreads) t0[q] = t0[R * m + q];
     }
   }
   __syncthreads();

@@ -96,6 +96,9 @@ def default_config(**overrides):
     cfg = AfcConfig()
     L.afc_default_config(C.byref(cfg))
     for k, v in overrides.items():
+        if k == "dbg":  # experiment switches (reserved[0])
+            cfg.reserved[0] = int(v)
+            continue
         if not hasattr(cfg, k):
             raise AfcError("unknown config key %r" % k)
         setattr(cfg, k, v)
