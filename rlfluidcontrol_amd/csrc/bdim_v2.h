@@ -901,18 +901,18 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
         mg_increment(F);
         mg_restrict(F, Cc);
       }
-      pf.mark(l == 0 ? PF_DOWN0 : PF_COARSE_DOWN);
+      pf.mark(l == 0 ? PF_DOWN0 : (24 + l));
     }
     float rr = 0.f;
     {
       const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
       mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
-      pf.mark(PF_COARSE_GS);
+      pf.mark(16 + kc);
     }
     for (int l = kc - 1; l >= 0; --l) {
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
       mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
-      pf.mark(l == 0 ? PF_RR : PF_COARSE_GS);
+      pf.mark(l == 0 ? PF_RR : (16 + l));
     }
     if (P.exact_sums) rr = seq_inner(L0, sm);
     if (rr < P.mg_tol) break;

@@ -273,7 +273,13 @@ class AFCEnv:
         """returns {phase: microseconds} accumulated by env 0 since the last call"""
         out = np.zeros(32, np.int64)
         self._ck(self._L.afc_profile_phases(self._h, int(enable), _np_ptr(out), 32), "afc_profile_phases")
-        return {k: out[i] / 100.0 for i, k in enumerate(self.PHASES)}
+        d = {k: out[i] / 100.0 for i, k in enumerate(self.PHASES)}
+        for l in range(1, 8):
+            if out[16 + l]:
+                d["up_L%d" % l] = out[16 + l] / 100.0
+            if out[24 + l]:
+                d["down_L%d" % l] = out[24 + l] / 100.0
+        return d
 
     # -- unit-level operators (parity tests) --
     def op_advdif(self, fx, fy, u0x, u0y):
