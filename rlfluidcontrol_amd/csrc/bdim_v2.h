@@ -29,6 +29,30 @@ __device__ __forceinline__ float quick_face(float bLm, float bL, float bH, float
   return ok ? lim : bf;
 }
 
+// The same for the x- and the y-component at once: both faces have the same geometry (same cells,
+// same fallback flags), so the arithmetic can use packed-f32 instructions (v_pk_add/mul_f32 --
+// per-component IEEE operations, nothing fused, bits unchanged).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, bool okL, bool okH) {
+  const f2 bf = 0.5f * (bL + bH);
+  const bool upx = uf.x > 0.f, upy = uf.y > 0.f;
+  f2 bc, bd, bu;
+  bc.x = upx ? bL.x : bH.x;
+  bd.x = upx ? bH.x : bL.x;
+  bu.x = upx ? bLm.x : bHp.x;
+  bc.y = upy ? bL.y : bH.y;
+  bd.y = upy ? bH.y : bL.y;
+  bu.y = upy ? bLm.y : bHp.y;
+  const f2 q = bf - (1.f / 6.f) * (bd - 2.f * bc + bu);
+  const f2 b1 = bu + 10.f * (bc - bu);
+  f2 r;
+  const float lx = __builtin_amdgcn_fmed3f(q.x, bc.x, __builtin_amdgcn_fmed3f(bc.x, bd.x, b1.x));
+  const float ly = __builtin_amdgcn_fmed3f(q.y, bc.y, __builtin_amdgcn_fmed3f(bc.y, bd.y, b1.y));
+  r.x = (upx ? okL : okH) ? lx : bf.x;
+  r.y = (upy ? okL : okH) ? ly : bf.y;
+  return r;
+}
+
 // F = (advection + nu*diffusion)(src)*dt + base on interior cells (VectorField.AdvDif,
 // VectorField.pde:170-179), streamed through an LDS tile of R+4 rows.  Wave w owns R/4
 // consecutive rows of the block and carries the east-face flux down the rows; lane l owns C
@@ -65,14 +89,14 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
 #define TY(gi, gj) ty[((gi) - (a - 2)) * m + (gj)]
     if (lane_on) {
       const int i_beg = a + wave * RW;
-      float fEx[C], fEy[C];
+      f2 fE2[C];
       for (int ii = 0; ii < RW; ++ii) {
         const int i = i_beg + ii;
         if (i > n - 2) break;
         const bool rok = (i >= 2) && (i <= n - 2);       // row part of the fallback test for cells of row i
         const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
         const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
-        float fSx = 0.f, fSy = 0.f;
+        f2 fS2 = {0.f, 0.f};
         // the lane's C cells are contiguous: one (4-byte aligned) C-float load/store per array
         const bool full = (j0 + C - 1 <= m - 2);
         float bxv[C], byv[C], oxv[C], oyv[C];
@@ -94,53 +118,32 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           const bool cok = (j >= 2) && (j <= m - 2);
           const bool cokN = (j + 1 >= 2) && (j + 1 <= m - 2);
           const bool cokS = (j - 1 >= 2) && (j - 1 <= m - 2);
-          const float xc = TX(i, j), yc = TY(i, j);
-          // ---------- x component (btype 1): VectorField.pde:183-188 ----------
-          {
-            float fW;
-            if (ii == 0) {
-              const float uo = 0.5f * (TX(i - 1, j) + xc);
-              fW = uo * quick_face(TX(i - 2, j), TX(i - 1, j), xc, TX(i + 1, j), uo, rokW && cok, rok && cok);
-            } else {
-              fW = fEx[e];
-            }
-            const float ue = 0.5f * (TX(i + 1, j) + xc);
-            const float fE = ue * quick_face(TX(i - 1, j), xc, TX(i + 1, j), TX(i + 2, j), ue, rok && cok, rokE && cok);
-            if (e == 0) {
-              const float vs = 0.5f * (yc + TY(i - 1, j));
-              fSx = vs * quick_face(TX(i, j - 2), TX(i, j - 1), xc, TX(i, j + 1), vs, rok && cokS, rok && cok);
-            }
-            const float vn = 0.5f * (TY(i, j + 1) + TY(i - 1, j + 1));
-            const float fN = vn * quick_face(TX(i, j - 1), xc, TX(i, j + 1), TX(i, j + 2), vn, rok && cok, rok && cokN);
-            const float adv = ((fW - fE) + (fSx - fN));
-            const float dif = TX(i + 1, j) + TX(i, j + 1) - 4 * xc + TX(i - 1, j) + TX(i, j - 1);  // :198-200
-            oxv[e] = (adv + nu * dif) * dt + bxv[e];  // :174
-            fEx[e] = fE;
-            fSx = fN;
+          // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
+#define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
+          const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
+          f2 fW;
+          if (ii == 0) {
+            const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
+            fW = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW && cok, rok && cok);
+          } else {
+            fW = fE2[e];
           }
-          // ---------- y component (btype 2): VectorField.pde:189-194 ----------
-          {
-            float fW;
-            if (ii == 0) {
-              const float uo = 0.5f * (TX(i, j - 1) + xc);
-              fW = uo * quick_face(TY(i - 2, j), TY(i - 1, j), yc, TY(i + 1, j), uo, rokW && cok, rok && cok);
-            } else {
-              fW = fEy[e];
-            }
-            const float ue = 0.5f * (TX(i + 1, j - 1) + TX(i + 1, j));
-            const float fE = ue * quick_face(TY(i - 1, j), yc, TY(i + 1, j), TY(i + 2, j), ue, rok && cok, rokE && cok);
-            if (e == 0) {
-              const float vs = 0.5f * (TY(i, j - 1) + yc);
-              fSy = vs * quick_face(TY(i, j - 2), TY(i, j - 1), yc, TY(i, j + 1), vs, rok && cokS, rok && cok);
-            }
-            const float vn = 0.5f * (yc + TY(i, j + 1));
-            const float fN = vn * quick_face(TY(i, j - 1), yc, TY(i, j + 1), TY(i, j + 2), vn, rok && cok, rok && cokN);
-            const float adv = ((fW - fE) + (fSy - fN));
-            const float dif = TY(i + 1, j) + TY(i, j + 1) - 4 * yc + TY(i - 1, j) + TY(i, j - 1);
-            oyv[e] = (adv + nu * dif) * dt + byv[e];  // :175
-            fEy[e] = fE;
-            fSy = fN;
+          const f2 ue = 0.5f * (f2{ce.x, TX(i + 1, j - 1)} + f2{cc.x, ce.x});
+          const f2 fE = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok && cok, rokE && cok);
+          if (e == 0) {
+            const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});  // x: y[i][j]+y[i-1][j]; y: y[i][j-1]+y[i][j]
+            fS2 = vs * quick_face2(XY(i, j - 2), cs, cc, cn, vs, rok && cokS, rok && cok);
           }
+          const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{TY(i - 1, j + 1), cn.y});
+          const f2 fN = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok && cok, rok && cokN);
+          const f2 adv = ((fW - fE) + (fS2 - fN));
+          const f2 dif = ce + cn - 4.f * cc + cw + cs;                           // :198-200
+          const f2 o = (adv + nu * dif) * dt + f2{bxv[e], byv[e]};              // :174-175
+          oxv[e] = o.x;
+          oyv[e] = o.y;
+          fE2[e] = fE;
+          fS2 = fN;
+#undef XY
         }
         if (full) {
           __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
