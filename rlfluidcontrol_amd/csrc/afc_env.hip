@@ -106,8 +106,10 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   s.xi2_m = P.act_scale * s.xi2;
   int steps = 0;
   bool got = false;
+  long long dbg_t0 = 0;
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
+    if ((P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
     step_dispatch<CPL>(P, e, s.xi1_m, s.xi2_m, &s.p_shift, sm, &sh, lds_dyn);
     ++steps;
     s.t += P.dt / P.resolution;
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
     done[e] = (!(s.t < P.end_time)) ? 1 : 0;
     if (nsteps) nsteps[e] = steps;
+    if (P.dbg & 8) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
+      obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
+      obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
+    }
     (void)got;
   }
 }

@@ -529,10 +529,12 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (need_r) pf.mark(PF_UP0);
     if (tid < 64) {
       const bool special = (I0 + 16 >= D.sp_i0) && (I0 - 3 <= D.sp_i1);
+      __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
         gs_march<false>(F, rr, dr, carry, zrow, dummy, I0);
       else
         gs_march<true>(F, rr, dr, carry, zrow, dummy, I0);
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     if (need_r) pf.mark(PF_GS0);
@@ -935,12 +937,22 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
                                        float *ax, float *ay) {
   const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  const int sp0 = P.lev[0].sp_i0, sp1 = P.lev[0].sp_i1;
+  const float cu = P.lev[0].cu;
   for (int q = threadIdx.x; q < n_ * CPR; q += kThreads) {
     const int g = q / CPR + 1, c4 = q - (g - 1) * CPR;
     const int k = g * m + 1 + 4 * c4;
     const F4 pc = load4u(p + k), pw = load4u(p + k - m);
     const float psl = p[k - 1];
-    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k), cx4 = load4u(G(P.cx) + k), cy4 = load4u(G(P.cy) + k);
+    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k);
+    F4 cx4, cy4;
+    if (g >= sp0 && g <= sp1) {  // rows that cross a body: the real coefficient arrays
+      cx4 = load4u(G(P.cx) + k);
+      cy4 = load4u(G(P.cy) + k);
+    } else {  // verified on the host: every face coefficient of the row equals cu (LevelDesc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cx4.v[e] = cy4.v[e] = cu;
+    }
     F4 un, vn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
