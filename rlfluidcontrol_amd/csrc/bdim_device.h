@@ -115,6 +115,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 struct Prof {
   long long *acc;
   long long last;
+  int stop = 0;  // diagnostic: leave the step after phase `stop` (per-phase HBM traffic by differencing)
   __device__ void start(const StepParams &P) {
     acc = (G(P.stamps) && blockIdx.x == 0 && threadIdx.x == 0) ? G(P.stamps) : nullptr;
     if (acc) last = wall_clock64();

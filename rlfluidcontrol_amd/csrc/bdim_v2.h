@@ -70,6 +70,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
   const int j0 = 1 + C * lane;
   const bool lane_on = (j0 <= m - 2);
   const float nu = P.nu, dt = P.dt;
+  const bool same = (bx == sx) && (by == sy);
   for (int a = 1; a <= n - 2; a += R) {
     // ---- stage rows a-2 .. a+R+1 of src into LDS (flat, coalesced float2) ----
     const int t0 = (a - 2) * m;                    // flat index of tile row 0
@@ -100,7 +101,14 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         // the lane's C cells are contiguous: one (4-byte aligned) C-float load/store per array
         const bool full = (j0 + C - 1 <= m - 2);
         float bxv[C], byv[C], oxv[C], oyv[C];
-        if (full) {
+        if (same) {  // predictor: the base field is the advected field, already in the tile
+#pragma unroll
+          for (int e = 0; e < C; ++e) {
+            const int jj = (j0 + e <= m - 2) ? j0 + e : m - 2;
+            bxv[e] = TX(i, jj);
+            byv[e] = TY(i, jj);
+          }
+        } else if (full) {
           __builtin_memcpy(bxv, bx + i * m + j0, sizeof(float) * C);
           __builtin_memcpy(byv, by + i * m + j0, sizeof(float) * C);
         } else {
@@ -395,6 +403,213 @@ __device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc
   return xc[((ci - 1) / 2 + 1) * mc + ((cj - 1) / 2 + 1)];
 }
 
+// ---- the two per-chunk bodies of the up-leg (4 columns of one row), split into "issue the global
+// loads" and "compute" so that the finest level can issue the loads while the march is running ----
+struct UpGeom {
+  const Lv *F, *Cc;
+  const LevelDesc *D;
+  int n, m, n_, m_, mc, PW, CPR;
+  float *rr, *dr;
+};
+struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
+  F4 r;
+  float a[4], w1, w2, e1, e2;
+};
+struct ExitIn {  // x of the chunk, the coarse x under it, the two x ghosts a boundary chunk mirrors into
+  F4 x;
+  float a1, a2, gl, gh;
+};
+
+__device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, int g, int c4) {
+  FillIn in;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) in.r.v[e] = in.a[e] = 0.f;
+  in.w1 = in.w2 = in.e1 = in.e2 = 0.f;
+  if (g <= U.n_) {
+    in.r = load4u(U.F->r + g * U.m + 1 + 4 * c4);
+    if (HASC) {
+      const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > U.n_) ? U.n_ : g + 1;
+      const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
+      const float *xw = U.Cc->x + ((gw - 1) / 2 + 1) * U.mc + 2 * c4;
+      const float *xe = U.Cc->x + ((ge - 1) / 2 + 1) * U.mc + 2 * c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) in.a[e] = xa[e];
+      in.w1 = xw[1];
+      in.w2 = xw[2];
+      in.e1 = xe[1];
+      in.e2 = xe[2];
+    }
+  }
+  return in;
+}
+
+// r (after the prolongation increment) and d0 = r*inv of one chunk -> rings
+__device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int g, int c4, const FillIn &in, bool sp) {
+  const int m = U.m, n_ = U.n_, m_ = U.m_, CPR = U.CPR;
+  const int j = 1 + 4 * c4;
+  const int sl = (g % kRing) * U.PW + j;
+  F4 rv = in.r, dv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dv.v[e] = 0.f;
+  if (g <= n_) {
+    const int kk = g * m + j;
+    F4 lw, le, ls, iv;
+    float ln4;
+    if (sp) {
+      lw = load4u(U.F->lx + kk);
+      le = load4u(U.F->lx + kk + m);
+      ls = load4u(U.F->ly + kk);
+      ln4 = U.F->ly[kk + 4];
+      iv = load4u(U.F->inv + kk);
+    } else {
+      float a0, a1, a2, a3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        coef_analytic(*U.D, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
+        lw.v[e] = a0;
+        le.v[e] = a1;
+        ls.v[e] = a2;
+        if (e == 3) ln4 = a3;
+      }
+    }
+    if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+      const float a1 = in.a[1], a2 = in.a[2];
+      const float a0 = (c4 == 0) ? a1 : in.a[0], a3 = (c4 == CPR - 1) ? a2 : in.a[3];
+      const float w1 = in.w1, w2 = in.w2, e1 = in.e1, e2 = in.e2;
+      const float dc[4] = {a1, a1, a2, a2}, dw[4] = {w1, w1, w2, w2}, de[4] = {e1, e1, e2, e2};
+      const float ds[4] = {a0, a1, a1, a2}, dn[4] = {a1, a2, a2, a3};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+        rv.v[e] = rv.v[e] - (dc[e] * diag + dw[e] * lw.v[e] + de[e] * le.v[e] + ds[e] * ls.v[e] + dn[e] * lnv);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    U.rr[sl + e] = rv.v[e];
+    U.dr[sl + e] = dv.v[e];
+  }
+  if (c4 == 0) U.dr[sl - 1] = 0.f;  // ghost columns of d0 read as zero
+  if (c4 == CPR - 1) U.dr[sl + 4] = 0.f;
+}
+
+__device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, int g, int c4) {
+  ExitIn in;
+  const int kk = g * U.m + 1 + 4 * c4;
+  in.x = load4u(U.F->x + kk);
+  in.a1 = in.a2 = in.gl = in.gh = 0.f;
+  if (HASC) {
+    const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
+    in.a1 = xa[1];
+    in.a2 = xa[2];
+  }
+  if (c4 == 0) in.gl = U.F->x[kk - 1];
+  if (c4 == U.CPR - 1) in.gh = U.F->x[kk + 4];
+  return in;
+}
+
+// d.setBC(); x += d (+ the ghosts that mirror the chunk); r -= A d   (MG.pde:90-97)
+__device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, const bool need_r, int g, int c4,
+                                           const ExitIn &in, bool sp, double &rr_part, double &xs_part, float &linf) {
+  const int n = U.n, m = U.m, n_ = U.n_, m_ = U.m_, CPR = U.CPR, PW = U.PW;
+  const Lv &F = *U.F;
+  float *rr = U.rr, *dr = U.dr;
+  const int j = 1 + 4 * c4, kk = g * m + j;
+  const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+  const int sl = (g % kRing) * PW + j;
+  float dp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (HASC) {
+    dp[0] = in.a1;
+    dp[1] = in.a1;
+    dp[2] = in.a2;
+    dp[3] = in.a2;
+  }
+  float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
+#pragma unroll
+  for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
+  if (c4 == 0) d6[0] = d6[1];
+  if (c4 == CPR - 1) d6[5] = d6[4];
+  F4 xn;
+  if (need_r) {
+    const float *dwp = dr + (gw % kRing) * PW + j, *dep = dr + (ge % kRing) * PW + j;
+    F4 lw, le, ls;
+    float ln4;
+    if (sp) {
+      lw = load4u(F.lx + kk);
+      le = load4u(F.lx + kk + m);
+      ls = load4u(F.ly + kk);
+      ln4 = F.ly[kk + 4];
+    } else {
+      float a0, a1, a2, a3, a4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        coef_analytic(*U.D, g, j + e, n_, m_, a0, a1, a2, a3, a4);
+        lw.v[e] = a0;
+        le.v[e] = a1;
+        ls.v[e] = a2;
+        if (e == 3) ln4 = a3;
+      }
+    }
+    F4 rn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+      const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+      const float d = d6[1 + e];
+      rn.v[e] = rr[sl + e] - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
+      const float pr = rn.v[e] * rn.v[e];
+      rr_part += (double)pr;
+      linf = jmax(linf, jabs(rn.v[e]));
+    }
+    store4u(F.r + kk, rn);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float xo = in.x.v[e];
+    if (HASC) xo = xo + dp[e];
+    xn.v[e] = xo + d6[1 + e];
+    if (need_r) xs_part += (double)xn.v[e];
+  }
+  store4u(F.x + kk, xn);
+  // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
+  if (c4 == 0) {
+    float xg = in.gl;
+    if (HASC) xg = xg + dp[0];
+    F.x[kk - 1] = xg + d6[1];
+  }
+  if (c4 == CPR - 1) {
+    float xg = in.gh;
+    if (HASC) xg = xg + dp[3];
+    F.x[kk + 4] = xg + d6[4];
+  }
+  if (g == 1 || g == n_) {
+    const int kg = ((g == 1) ? 0 : (n - 1)) * m + j;
+    const F4 xg4 = load4u(F.x + kg);
+    F4 xgn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xg = xg4.v[e];
+      if (HASC) xg = xg + dp[e];
+      xgn.v[e] = xg + d6[1 + e];
+    }
+    store4u(F.x + kg, xgn);
+    if (c4 == 0) {
+      float xg = F.x[kg - 1];
+      if (HASC) xg = xg + dp[0];
+      F.x[kg - 1] = xg + d6[1];
+    }
+    if (c4 == CPR - 1) {
+      float xg = F.x[kg + 4];
+      if (HASC) xg = xg + dp[3];
+      F.x[kg + 4] = xg + d6[4];
+    }
+  }
+}
+
 // One call = everything a level does on the way up (MG.pde:73-76 seen from the level itself):
 //   HASC:  d = prolongate(coarse.x); increment()            [x += d, r -= A d]
 //   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
@@ -416,6 +631,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   float linf = 0.f;
   const int CPR = m_ >> 2;
   const bool chunked = ((m_ & 3) == 0);
+  const UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr};
   __syncthreads();
   // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
   // (the region is shared with the other phases' tiles, so this is redone on every call)
@@ -431,60 +647,8 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       const int nrow = hi - loaded;
       for (int q = tid; q < nrow * CPR; q += kThreads) {
         const int t = q / CPR, c4 = q - t * CPR;
-        const int g = loaded + 1 + t, j = 1 + 4 * c4;
-        const int sl = (g % kRing) * PW + j;
-        F4 rv, dv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rv.v[e] = dv.v[e] = 0.f;
-        if (g <= n_) {
-          const int kk = g * m + j;
-          rv = load4u(F.r + kk);
-          F4 lw, le, ls, iv;
-          float ln4;
-          if (sp_fill) {
-            lw = load4u(F.lx + kk);
-            le = load4u(F.lx + kk + m);
-            ls = load4u(F.ly + kk);
-            ln4 = F.ly[kk + 4];
-            iv = load4u(F.inv + kk);
-          } else {
-            float a0, a1, a2, a3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              coef_analytic(D, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
-              lw.v[e] = a0;
-              le.v[e] = a1;
-              ls.v[e] = a2;
-              if (e == 3) ln4 = a3;
-            }
-          }
-          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
-            const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
-            const float *xa = Cc.x + ((g - 1) / 2 + 1) * mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
-            const float *xw = Cc.x + ((gw - 1) / 2 + 1) * mc + 2 * c4;
-            const float *xe = Cc.x + ((ge - 1) / 2 + 1) * mc + 2 * c4;
-            const float a1 = xa[1], a2 = xa[2];
-            const float a0 = (c4 == 0) ? a1 : xa[0], a3 = (c4 == CPR - 1) ? a2 : xa[3];
-            const float w1 = xw[1], w2 = xw[2], e1 = xe[1], e2 = xe[2];
-            const float dc[4] = {a1, a1, a2, a2}, dw[4] = {w1, w1, w2, w2}, de[4] = {e1, e1, e2, e2};
-            const float ds[4] = {a0, a1, a1, a2}, dn[4] = {a1, a2, a2, a3};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
-              const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
-              rv.v[e] = rv.v[e] - (dc[e] * diag + dw[e] * lw.v[e] + de[e] * le.v[e] + ds[e] * ls.v[e] + dn[e] * lnv);
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          rr[sl + e] = rv.v[e];
-          dr[sl + e] = dv.v[e];
-        }
-        if (c4 == 0) dr[sl - 1] = 0.f;        // ghost columns of d0 read as zero
-        if (c4 == CPR - 1) dr[sl + 4] = 0.f;
+        const FillIn in = fill_load(U, HASC, loaded + 1 + t, c4);
+        fill_apply(U, HASC, loaded + 1 + t, c4, in, sp_fill);
       }
     } else
     {
@@ -545,90 +709,8 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       const int nrow = e1 - e0 + 1;
       for (int q = tid; q < nrow * CPR; q += kThreads) {
         const int t = q / CPR, c4 = q - t * CPR;
-        const int g = e0 + t, j = 1 + 4 * c4, kk = g * m + j;
-        const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
-        const int sl = (g % kRing) * PW + j;
-        const F4 x4 = load4u(F.x + kk);
-        float dp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HASC) {
-          const float *xa = Cc.x + ((g - 1) / 2 + 1) * mc + 2 * c4;
-          const float a1 = xa[1], a2 = xa[2];
-          dp[0] = a1;
-          dp[1] = a1;
-          dp[2] = a2;
-          dp[3] = a2;
-        }
-        float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
-#pragma unroll
-        for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
-        if (c4 == 0) d6[0] = d6[1];
-        if (c4 == CPR - 1) d6[5] = d6[4];
-        F4 xn;
-        if (need_r) {
-          const float *dwp = dr + (gw % kRing) * PW + j, *dep = dr + (ge % kRing) * PW + j;
-          F4 lw, le, ls;
-          float ln4;
-          if (sp_exit) {
-            lw = load4u(F.lx + kk);
-            le = load4u(F.lx + kk + m);
-            ls = load4u(F.ly + kk);
-            ln4 = F.ly[kk + 4];
-          } else {
-            float a0, a1, a2, a3, a4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              coef_analytic(D, g, j + e, n_, m_, a0, a1, a2, a3, a4);
-              lw.v[e] = a0;
-              le.v[e] = a1;
-              ls.v[e] = a2;
-              if (e == 3) ln4 = a3;
-            }
-          }
-          F4 rn;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
-            const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
-            const float d = d6[1 + e];
-            rn.v[e] = rr[sl + e] - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
-            const float pr = rn.v[e] * rn.v[e];
-            rr_part += (double)pr;
-            linf = jmax(linf, jabs(rn.v[e]));
-          }
-          store4u(F.r + kk, rn);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float xo = x4.v[e];
-          if (HASC) xo = xo + dp[e];
-          xn.v[e] = xo + d6[1 + e];
-          if (need_r) xs_part += (double)xn.v[e];
-        }
-        store4u(F.x + kk, xn);
-        // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
-#define GHOST1(KG, E)                     \
-  {                                       \
-    float xg = F.x[KG];                   \
-    if (HASC) xg = xg + dp[E];            \
-    F.x[KG] = xg + d6[1 + (E)];           \
-  }
-        if (c4 == 0) GHOST1(kk - 1, 0)
-        if (c4 == CPR - 1) GHOST1(kk + 4, 3)
-        if (g == 1 || g == n_) {
-          const int kg = ((g == 1) ? 0 : (n - 1)) * m + j;
-          const F4 xg4 = load4u(F.x + kg);
-          F4 xgn;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float xg = xg4.v[e];
-            if (HASC) xg = xg + dp[e];
-            xgn.v[e] = xg + d6[1 + e];
-          }
-          store4u(F.x + kg, xgn);
-          if (c4 == 0) GHOST1(kg - 1, 0)
-          if (c4 == CPR - 1) GHOST1(kg + 4, 3)
-        }
-#undef GHOST1
+        const ExitIn in = exit_load(U, HASC, e0 + t, c4);
+        exit_apply(U, HASC, need_r, e0 + t, c4, in, sp_exit, rr_part, xs_part, linf);
       }
     } else
     {
@@ -716,7 +798,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
 // RESID = true : finest level, first iteration: r0 = div(u) - A (pin+s), x_out = (pin+s) + d
 // RESID = false: any level with an existing residual: r0 = F.r, x_out = F.x + d  (F.x is 0 on
 //                coarse levels, MG.pde:56; on the finest level it is the current iterate)
-template <bool RESID>
+template <bool RESID, bool XZ>
 __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift,
                                      float *lds) {
@@ -731,7 +813,6 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   const int tid = threadIdx.x;
   const int m1 = L1.m;
   const bool uni = (D.zero_bnd == 0);  // finest level: all coefficients uniform outside the special rows
-  for (int q = tid; q < L1.n * L1.m; q += kThreads) L1.x[q] = 0.f;  // MG.pde:56
   // rows per block: 14 on the finest grids; on narrow (coarse) levels enough rows to give every
   // thread a patch (7*k*CPR patches per block), bounded by the 2080-float tile
   int kblk = 1;
@@ -841,7 +922,13 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
             if (e == 3) ln4 = a3;
           }
         }
-        const F4 pc = load4u(pin + k);
+        F4 pc;  // x before the increment: the iterate on the finest level, exactly zero on coarse ones (MG.pde:56)
+        if (!XZ) {
+          pc = load4u(pin + k);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pc.v[e] = 0.f;
+        }
         const float *r0row = t0 + (gg - (a - 1)) * m + j;
         F4 xo, ro;
 #pragma unroll
@@ -858,18 +945,24 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
         store4u(pout + k, xo);
         store4u(r + k, ro);
         // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
-        if (c4 == 0) pout[k - 1] = (pin[k - 1] + shift) + dd[1 + h][1];
-        if (c4 == CPR - 1) pout[k + 4] = (pin[k + 4] + shift) + dd[1 + h][4];
+        if (c4 == 0) pout[k - 1] = ((XZ ? 0.f : pin[k - 1]) + shift) + dd[1 + h][1];
+        if (c4 == CPR - 1) pout[k + 4] = ((XZ ? 0.f : pin[k + 4]) + shift) + dd[1 + h][4];
         const bool top = (gg == 1), bot = (gg == n_);
         if (top || bot) {
           const int kg = (top ? 0 : (n - 1)) * m + j;
-          const F4 pg = load4u(pin + kg);
+          F4 pg;
+          if (!XZ) {
+            pg = load4u(pin + kg);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pg.v[e] = 0.f;
+          }
           F4 xg;
 #pragma unroll
           for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + dd[1 + h][1 + e];
           store4u(pout + kg, xg);
-          if (c4 == 0) pout[kg - 1] = (pin[kg - 1] + shift) + dd[1 + h][1];
-          if (c4 == CPR - 1) pout[kg + 4] = (pin[kg + 4] + shift) + dd[1 + h][4];
+          if (c4 == 0) pout[kg - 1] = ((XZ ? 0.f : pin[kg - 1]) + shift) + dd[1 + h][1];
+          if (c4 == CPR - 1) pout[kg + 4] = ((XZ ? 0.f : pin[kg + 4]) + shift) + dd[1 + h][4];
         }
       }
       // restrict (MG.pde:124-137): sum of the 2x2 children, reference order
@@ -898,23 +991,33 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
       if (l == 0 && iter == 1 && fused_head) {
-        mg_down_fused<true>(P, L0, Cc, ux, uy, pin, shift, lds);
+        mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
       } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
-        mg_down_fused<false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
+        if (l == 0)
+          mg_down_fused<false, false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
+        else  // coarse levels start from x = 0 (MG.pde:56): folded into the leg, never stored or re-read
+          mg_down_fused<false, true>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
       } else {
+        if (l > 0) {  // x = 0 on entry (MG.pde:56); the fused legs fold this into their arithmetic
+          for (int q = threadIdx.x; q < F.n * F.m; q += kThreads) F.x[q] = 0.f;
+          __syncthreads();
+        }
         mg_dinv(F);  // smooth(0)
         mg_increment(F);
         mg_restrict(F, Cc);
       }
       pf.mark(l == 0 ? PF_DOWN0 : (24 + l));
+      if (l == 0 && pf.stop == 3) return iter;
     }
     float rr = 0.f;
     {
       const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
+      for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
       mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
     }
     for (int l = kc - 1; l >= 0; --l) {
+      if (l == 0 && pf.stop == 4) return iter;
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
       mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
       pf.mark(l == 0 ? PF_RR : (16 + l));
@@ -939,10 +1042,18 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
   const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
   const int sp0 = P.lev[0].sp_i0, sp1 = P.lev[0].sp_i1;
   const float cu = P.lev[0].cu;
-  for (int q = threadIdx.x; q < n_ * CPR; q += kThreads) {
-    const int g = q / CPR + 1, c4 = q - (g - 1) * CPR;
+  // a thread walks down one 4-column chunk through its group's rows, so the row above (p west of
+  // the x-faces) is the chunk it read one iteration earlier and p crosses HBM once
+  const int ngrp = kThreads / CPR, rg = threadIdx.x / CPR, c4 = threadIdx.x - rg * CPR;
+  const int rpg = (n_ + ngrp - 1) / ngrp;
+  const int g_beg = 1 + rg * rpg, g_end = (rg >= ngrp) ? 0 : ((g_beg + rpg - 1 > n_) ? n_ : g_beg + rpg - 1);
+  F4 pprev;
+  for (int g = g_beg; g <= g_end; ++g) {
     const int k = g * m + 1 + 4 * c4;
-    const F4 pc = load4u(p + k), pw = load4u(p + k - m);
+    const F4 pc = load4u(p + k);
+    if (g == g_beg) pprev = load4u(p + k - m);
+    const F4 pw = pprev;
+    pprev = pc;
     const float psl = p[k - 1];
     const F4 u4 = load4u(vx + k), v4 = load4u(vy + k);
     F4 cx4, cy4;
@@ -1008,6 +1119,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   L0.d = G(P.u0y) + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
   float xsum = 0.f;
   const int iters = mg_solve_v2(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
+  if (pf.stop >= 3 && pf.stop <= 5) return iters;
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
   const float shift = -1 * psum / (float)((P.n - 2) * (P.m - 2));  // VectorField.pde:136
@@ -1030,6 +1142,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   float shift = *pshift;
   Prof pf;
   pf.start(P);
+  pf.stop = (P.dbg >> 12) & 15;
   // half 0 = predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP                    -> B
   // half 1 = corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; (u+us)/2 -> C, A
   int its[2] = {0, 0};
@@ -1042,12 +1155,17 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     float *pout = half ? p0 : p1;
     advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
     pf.mark(PF_ADVDIF);
+    if (pf.stop == 1 + 8 * half) return;
     forcing_band(P, dx, dy, scratch, dphi1, dphi2);
     pf.mark(PF_FORCING);
     setbc_vel(P, dx, dy, lds);
     pf.mark(PF_SETBC);
+    if (pf.stop == 2 + 8 * half) return;
     float l;
+    if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
     const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds);
+    if (pf.stop >= 3 && pf.stop <= 6) return;
+    if (pf.stop) pf.stop += 8 * half;
     if (half) {
       its[1] = it;
       lin[1] = l;

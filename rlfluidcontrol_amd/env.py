@@ -52,10 +52,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("AFC_ENV_LIB", LIB_PATH)  # override: A/B runs of two builds on one GPU box
+    if not os.path.exists(path):
         raise AfcError("libafc_env.so is missing: build it with `python -m rlfluidcontrol_amd.build` "
                        "(the product has no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p
     L.afc_last_error.restype = C.c_char_p
     L.afc_default_config.argtypes = [C.POINTER(AfcConfig)]

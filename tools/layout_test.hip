@@ -7,10 +7,10 @@
 struct F4 { float v[4]; };
 __device__ inline F4 ld(const float* p) { F4 r; __builtin_memcpy(&r, p, 16); return r; }
 __device__ inline void st(float* p, F4 v) { __builtin_memcpy(p, &v, 16); }
-__global__ __launch_bounds__(256, 4) void k(float* base, size_t env_stride, size_t field_stride, int ncell, int reps) {
+__global__ __launch_bounds__(256, 4) void k(float* base, size_t env_stride, size_t field_stride, int ncell, int reps, int off) {
   extern __shared__ float lds[];
   lds[threadIdx.x] = 0.f;
-  float* b = base + blockIdx.x * env_stride;
+  float* b = base + blockIdx.x * env_stride + off;
   for (int r = 0; r < reps; ++r)
     for (int q = threadIdx.x * 4; q + 3 < ncell; q += 1024) {
       F4 a0 = ld(b + q), a1 = ld(b + field_stride + q), a2 = ld(b + 2 * field_stride + q), a3 = ld(b + 3 * field_stride + q),
@@ -34,17 +34,18 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int layout = 0; layout < 2; ++layout) {
-    const size_t es = layout ? NF * Ns : Ns, fs = layout ? Ns : (size_t)E * Ns;
+  for (int layout = 0; layout < 3; ++layout) {
+    const size_t es = (layout == 1) ? NF * Ns : Ns, fs = (layout == 1) ? Ns : (size_t)E * Ns;
+    const int off = (layout == 2) ? 1 : 0;  // 2: field-major, every 16-byte access 4 bytes off alignment
     for (int it = 0; it < 3; ++it) {
       hipEventRecord(e0);
-      k<<<E, 256, 38 * 1024>>>(d, es, fs, ncell, 8);
+      k<<<E, 256, 38 * 1024>>>(d, es, fs, ncell - 4, 8, off);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
-      const double bytes = (double)E * ncell * 4 * NF * 8;
-      printf("E=%d layout=%s: %.3f ms  %.2f TB/s  (%.1f us per pass per env)\n", E, layout ? "env-major" : "field-major", ms,
+      const double bytes = (double)E * (ncell - 4) * 4 * NF * 8;
+      printf("E=%d layout=%s: %.3f ms  %.2f TB/s  (%.1f us per pass per env)\n", E, layout == 1 ? "env-major" : (layout == 2 ? "field-major+4B" : "field-major"), ms,
              bytes / ms / 1e9, ms * 1e3 / 8);
     }
   }

@@ -1,0 +1,66 @@
+"""HBM bytes per phase of one sim-step, by differencing launches that leave the step early.
+Run twice under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE); then `phase_traffic.py report <dirF> <dirW>`.
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out_f -- python3 tools/phase_traffic.py run"""
+import csv
+import glob
+import os
+import sys
+
+import numpy as np
+
+STOPS = [1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 0]
+NAMES = ["advdif", "forcing+setbc", "head(down0)", "coarse levels", "up0 (L0 fill/march/exit)", "project tail"]
+REP = 3
+E = 1024
+
+
+def run():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rlfluidcontrol_amd import build, env
+    build.build()
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "wake_res16_re100.npz"))
+    for st in STOPS:
+        g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=st << 12)
+        g.set_reset_state(z["u"], z["v"], z["p"])
+        g.reset()
+        xi = np.zeros((E, 2), np.float32)
+        for _ in range(REP):
+            g.update2(xi)
+        g.close()
+
+
+def series(d, counter):
+    rows = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_sim_step" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    rows.sort()
+    agg = {}
+    for did, v in rows:
+        agg[did] = agg.get(did, 0.0) + v
+    vals = [agg[k] for k in sorted(agg)]
+    assert len(vals) == REP * len(STOPS), len(vals)
+    return [min(vals[i * REP:(i + 1) * REP][1:]) for i in range(len(STOPS))]  # skip each env's first launch
+
+
+def report(df, dw):
+    f = [2 * 1024 * v for v in series(df, "FETCH_SIZE")]  # gfx950: x2, KiB
+    w = [1024 * v for v in series(dw, "WRITE_SIZE")]
+    cells = E * 256 * 128
+    prev_f = prev_w = 0.0
+    print("%-34s %10s %10s   (floats per cell)" % ("phase", "read", "write"))
+    for i, st in enumerate(STOPS):
+        if st == 0:
+            print("%-34s %10.2f %10.2f" % ("whole step", f[i] / cells / 4, w[i] / cells / 4))
+            continue
+        half, ph = divmod(st - 1, 8)
+        print("%-34s %10.2f %10.2f" % ("half %d %s" % (half, NAMES[ph]), (f[i] - prev_f) / cells / 4, (w[i] - prev_w) / cells / 4))
+        prev_f, prev_w = f[i], w[i]
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run()
+    else:
+        report(sys.argv[2], sys.argv[3])
