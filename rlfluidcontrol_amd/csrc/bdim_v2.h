@@ -410,6 +410,8 @@ struct UpGeom {
   const LevelDesc *D;
   int n, m, n_, m_, mc, PW, CPR;
   float *rr, *dr;
+  bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
+  bool update_x = true;  // false: replay that only materialises r
 };
 struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
   F4 r;
@@ -500,8 +502,13 @@ __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int
 __device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, int g, int c4) {
   ExitIn in;
   const int kk = g * U.m + 1 + 4 * c4;
-  in.x = load4u(U.F->x + kk);
   in.a1 = in.a2 = in.gl = in.gh = 0.f;
+  if (!U.update_x) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) in.x.v[e] = 0.f;
+    return in;
+  }
+  in.x = load4u(U.F->x + kk);
   if (HASC) {
     const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
     in.a1 = xa[1];
@@ -565,8 +572,9 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
       rr_part += (double)pr;
       linf = jmax(linf, jabs(rn.v[e]));
     }
-    store4u(F.r + kk, rn);
+    if (U.store_r) store4u(F.r + kk, rn);
   }
+  if (!U.update_x) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float xo = in.x.v[e];
@@ -617,7 +625,9 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
 // need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
 __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
                                     float *rr_out,
-                                    float *linf_out, Prof &pf, float *xsum_out = nullptr) {
+                                    float *linf_out, Prof &pf, float *xsum_out = nullptr, const int rmode = 0) {
+  // rmode (finest level, chunked path): 0 = r written back; 1 = r not written back (the caller replays
+  // with rmode 2 in the rare case a second V-cycle needs it); 2 = replay: same d, only r is stored
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   const int PW = m + kPad;
   float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
@@ -631,7 +641,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   float linf = 0.f;
   const int CPR = m_ >> 2;
   const bool chunked = ((m_ & 3) == 0);
-  const UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr};
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr};
+  U.store_r = (rmode != 1);
+  U.update_x = (rmode != 2);
   __syncthreads();
   // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
   // (the region is shared with the other phases' tiles, so this is redone on every call)
@@ -778,7 +790,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     __syncthreads();  // the next strip's fill re-uses ring slots this exit has just read
     if (need_r) pf.mark(PF_INC0);
   }
-  if (need_r) {
+  if (need_r && rmode != 2) {
     *rr_out = (float)block_sum_d(rr_part, sm);
     *linf_out = block_max_f(linf, sm);
     if (xsum_out) *xsum_out = (float)block_sum_d(xs_part, sm);
@@ -1019,7 +1031,14 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     for (int l = kc - 1; l >= 0; --l) {
       if (l == 0 && pf.stop == 4) return iter;
       const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
-      mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum);
+      // the finest level's new r is only read again by a further V-cycle (or by the sequential
+      // inner product of the parity mode): normally it is not written back at all
+      const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(P.dbg & 2);
+      mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
+        float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
+        mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+      }
       pf.mark(l == 0 ? PF_RR : (16 + l));
     }
     if (P.exact_sums) rr = seq_inner(L0, sm);

@@ -195,3 +195,30 @@ def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init, 
     assert np.array_equal(g.probes(32)[0], o.probes(32))
     _, rg = g.solver_stats()
     g.close()
+
+
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100)])
+def test_lazy_residual_writeback_is_invisible(envmod, res, Re):
+    """Default mode does not write the finest-level residual back unless a second V-cycle needs it
+    (then the level is replayed).  Same fields, bit for bit, as always writing it (dbg switch 2),
+    on a cold start whose first steps do take several V-cycles."""
+    E = 2
+    ga = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re)
+    gb = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re, dbg=2)
+    rng = np.random.default_rng(11)
+    acts = (5 * rng.uniform(-1, 1, size=(12, E, 2))).astype(np.float32)
+    max_it = 0
+    for k in range(12):
+        fa = ga.update2(acts[k])
+        fb = gb.update2(acts[k])
+        assert np.array_equal(fa, fb), k
+        ita, _ = ga.solver_stats()
+        itb, _ = gb.solver_stats()
+        assert np.array_equal(ita, itb)
+        max_it = max(max_it, int(ita.max()))
+    assert max_it >= 2, "the run never needed a second V-cycle: replay path not exercised"
+    for e in range(E):
+        for a, b in zip(ga.get_state(e), gb.get_state(e)):
+            assert np.array_equal(a, b)
+    ga.close()
+    gb.close()
