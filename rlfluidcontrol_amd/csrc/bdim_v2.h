@@ -283,7 +283,7 @@ __device__ __forceinline__ void coef_analytic(const LevelDesc &D, int i, int j, 
 // are unconditional -- zeros into a pad or the dummy row.
 constexpr int kPad = 28;
 
-template <bool FAST>
+template <bool FAST, bool ZB = true>
 __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr, float *carry, float *zrow,
                                          float *dummy, int I0) {
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = m + kPad;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
     iv2 = D.invtab[3 * rc + 2];
   }
   const float cu = D.cu;
-  const bool zb = D.zero_bnd != 0;
+  const bool zb = ZB && D.zero_bnd != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
   const int steps = (m_ + 18 + 3) & ~3;  // multiple of 4 (the extra steps are inactive)
   const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
   // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k).  Operands of
@@ -312,13 +312,16 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
   // chunk ahead.
   const int jo = 1 - c - k;
   const float *p_rv = (row_ok ? rr + slot : zrow) + jo;
-  // lanes c == 0 take d[i-1][j] (sweep k) and d[i][j+1] (sweep k-1) from the carry rows; sweep 0
-  // takes d0[i][j+1] through the same register (DPP keeps `old` where no lane feeds it)
-  const float *p_cW = carry + k * PW + jo;
+  // lanes c == 0 take d[i-1][j] (sweep k) and d[i][j+1] (sweep k-1) from the carry rows (sweep 3: from
+  // the ring itself, where the previous strip left its final d); sweep 0 takes d0[i][j+1] through
+  // the same register (DPP keeps `old` where no lane feeds it)
+  const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
+  const float *p_cW = ((k == 3) ? (rowW_ok ? dr + ((i - 1) % kRing) * PW : zrow) : carry + k * PW) + jo;
   const float *p_cN = (k == 0) ? ((row_ok ? dr + slot : zrow) + 1 + jo) : (carry + (k - 1) * PW + 1 + jo);
   const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;
-  float *w_d = ((row_ok && k == 3) ? dr + slot : dummy) + jo;
-  float *w_c = ((c == 15) ? carry + k * PW : dummy) + jo;
+  // one LDS write per step: sweep 3 leaves the final d in the ring, the last row of sweeps 0-2 feeds
+  // the next strip through the carry rows, everything else goes to the dummy row
+  float *w_d = ((k == 3) ? (row_ok ? dr + slot : dummy) : ((c == 15) ? carry + k * PW : dummy)) + jo;
   float o_rv[4], o_cW[4], o_cN[4], o_dE[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -342,6 +345,41 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
   }
   if (!FAST) GS_CHUNK(0, x_lw, x_le, x_ls, x_iv, x_ln4)
   float res = 0.f;
+  // strips whose 19 rows all lie inside the grid have a stretch of steps in which every lane is at an
+  // interior column 2..m_-1: no lane needs the activity mask or a boundary inverse there
+  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
+  // one 4-step chunk; STEADY: no activity mask, interior inverse diagonal
+#define GS_STEPS(STEADY)                                                                                               \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                      \
+    float lw, le, ls, ln, iv;                                                                                          \
+    if (FAST) {                                                                                                        \
+      /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:         */ \
+      /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                       */ \
+      lw = le = ls = ln = cu;                                                                                          \
+      iv = iv0;                                                                                                        \
+      if (zb && !(STEADY)) {                                                                                           \
+        const int j = jb + e;                                                                                          \
+        iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                                 \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      lw = c_lw.v[e];                                                                                                  \
+      le = c_le.v[e];                                                                                                  \
+      ls = c_ls.v[e];                                                                                                  \
+      ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                      \
+      iv = c_iv.v[e];                                                                                                  \
+    }                                                                                                                  \
+    const float prev = res;                                                                                            \
+    const float up16 = lane_minus16(prev, lane);  /* (k-1, c): sweep k-1 at (i+1, j) */                                \
+    const float dW = dpp_row_shr1(o_cW[e], prev); /* (k, c-1): sweep k at (i-1, j); c == 0: carry / ring */            \
+    /* (k-1, c-1): sweep k-1 at (i, j+1); c == 0: carry; sweep 0 (DPP row 0 disabled): d0[i][j+1] */                   \
+    const float dN = __builtin_bit_cast(                                                                               \
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, o_cN[e]), __builtin_bit_cast(int, up16), 0x111,     \
+                                           0xE, 0xF, false));                                                          \
+    const float dE = (k == 0) ? o_dE[e] : up16;                                                                        \
+    const float v = -(dW * lw + dE * le + prev * ls + dN * ln - o_rv[e]) * iv; /* MG.pde:84-88 */                      \
+    res = ((STEADY) || (unsigned)(jb + e - 1) < m_eff) ? v : 0.f;                                                      \
+    qw_d[e] = res;                                                                                                     \
+  }
   for (int tau0 = 0; tau0 < steps; tau0 += 4) {
     if (!FAST) {
       c_lw = x_lw;
@@ -351,39 +389,12 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       c_ln4 = x_ln4;
       GS_CHUNK(tau0 + 4, x_lw, x_le, x_ls, x_iv, x_ln4)
     }
-    float *qw_d = w_d + tau0, *qw_c = w_c + tau0;
+    float *qw_d = w_d + tau0;
     const int jb = tau0 + jo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float lw, le, ls, ln, iv;
-      if (FAST) {
-        // every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform
-        // coefficient: cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).
-        lw = le = ls = ln = cu;
-        iv = iv0;
-        if (zb) {
-          const int j = jb + e;
-          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);
-        }
-      } else {
-        lw = c_lw.v[e];
-        le = c_le.v[e];
-        ls = c_ls.v[e];
-        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;
-        iv = c_iv.v[e];
-      }
-      const float prev = res;
-      const float up16 = lane_minus16(prev, lane);        // (k-1, c): sweep k-1 at (i+1, j)
-      const float dW = dpp_row_shr1(o_cW[e], prev);       // (k, c-1): sweep k at (i-1, j); c == 0: carry
-      // (k-1, c-1): sweep k-1 at (i, j+1); c == 0: carry; sweep 0 (DPP row 0 disabled): d0[i][j+1]
-      const float dN = __builtin_bit_cast(
-          float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, o_cN[e]), __builtin_bit_cast(int, up16), 0x111,
-                                             0xE, 0xF, false));
-      const float dE = (k == 0) ? o_dE[e] : up16;
-      const float v = -(dW * lw + dE * le + prev * ls + dN * ln - o_rv[e]) * iv;  // MG.pde:84-88
-      res = ((unsigned)(jb + e - 1) < m_eff) ? v : 0.f;
-      qw_d[e] = res;
-      qw_c[e] = res;
+    if (FAST && all_rows && tau0 >= 20 && tau0 + 3 <= m_ - 2) {
+      GS_STEPS(true)
+    } else {
+      GS_STEPS(false)
     }
     const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4;
 #pragma unroll
@@ -394,6 +405,7 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       o_dE[e] = q_dE[e];
     }
   }
+#undef GS_STEPS
 #undef GS_CHUNK
 }
 
@@ -708,8 +720,10 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
         gs_march<false>(F, rr, dr, carry, zrow, dummy, I0);
+      else if (D.zero_bnd)
+        gs_march<true, true>(F, rr, dr, carry, zrow, dummy, I0);
       else
-        gs_march<true>(F, rr, dr, carry, zrow, dummy, I0);
+        gs_march<true, false>(F, rr, dr, carry, zrow, dummy, I0);
       __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
