@@ -10,6 +10,13 @@
 
 namespace afc {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store of the wave (s_waitcnt vmcnt(0)), which puts a store round trip on the critical path
+// of each tile of a streaming loop; inside those loops nothing read from global memory was written
+// by this workgroup in the same phase, so only the LDS hand-over needs ordering.  Phase boundaries
+// keep __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
 // flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
@@ -76,7 +83,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
     const int t0 = (a - 2) * m;                    // flat index of tile row 0
     const int lo = t0 < 0 ? 0 : t0;
     const int hi = ((a + R + 2) * m < N) ? (a + R + 2) * m : N;
-    __syncthreads();  // previous block's readers are done
+    lds_barrier();  // previous block's readers are done
     for (int q = lo + 2 * threadIdx.x; q < hi; q += 2 * kThreads) {
       const float2 vx = *reinterpret_cast<const float2 *>(sx + q);
       const float2 vy = *reinterpret_cast<const float2 *>(sy + q);
@@ -85,7 +92,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
       ty[q - t0] = vy.x;
       ty[q - t0 + 1] = vy.y;
     }
-    __syncthreads();
+    lds_barrier();
 #define TX(gi, gj) tx[((gi) - (a - 2)) * m + (gj)]
 #define TY(gi, gj) ty[((gi) - (a - 2)) * m + (gj)]
     if (lane_on) {
@@ -660,7 +667,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
   // (the region is shared with the other phases' tiles, so this is redone on every call)
   for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
-  __syncthreads();
+  lds_barrier();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
   for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
     // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
@@ -713,7 +720,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       }
     }
     loaded = hi;
-    __syncthreads();
+    lds_barrier();
     if (need_r) pf.mark(PF_UP0);
     if (tid < 64) {
       const bool special = (I0 + 16 >= D.sp_i0) && (I0 - 3 <= D.sp_i1);
@@ -726,7 +733,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
         gs_march<true, false>(F, rr, dr, carry, zrow, dummy, I0);
       __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
+    lds_barrier();
     if (need_r) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
@@ -801,9 +808,10 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
         }
       }
     }
-    __syncthreads();  // the next strip's fill re-uses ring slots this exit has just read
+    lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
     if (need_r) pf.mark(PF_INC0);
   }
+  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
   if (need_r && rmode != 2) {
     *rr_out = (float)block_sum_d(rr_part, sm);
     *linf_out = block_max_f(linf, sm);
@@ -850,7 +858,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   const int R = 14 * kblk, TR = R + 2, NPAIR = 7 * kblk;
   for (int a = 1; a <= n_; a += R) {
     const bool sp = (a + R + 1 >= D.sp_i0) && (a - 2 <= D.sp_i1);
-    __syncthreads();
+    lds_barrier();
     // ---- step 1: r0 for rows a-1 .. a+R ----
     for (int q = tid; q < TR * CPR; q += kThreads) {
       const int t = q / CPR, c4 = q - t * CPR;
@@ -894,7 +902,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
 #pragma unroll
       for (int e = 0; e < 4; ++e) t0[t * m + j + e] = r0.v[e];
     }
-    __syncthreads();
+    lds_barrier();
     // ---- step 2: one 2x4 patch per thread ----
     for (int q = tid; q < NPAIR * CPR; q += kThreads) {
       const int pr = q / CPR, c4 = q - pr * CPR;
@@ -997,7 +1005,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
       L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
     }
     if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row 14) must keep its ORIGINAL r
-      __syncthreads();
+      lds_barrier();
       for (int q = tid; q < m; q += kThreads) t0[q] = t0[R * m + q];
     }
   }
