@@ -59,8 +59,26 @@ def report(df, dw):
         prev_f, prev_w = f[i], w[i]
 
 
+def report_insts(d):
+    """per-phase vector-memory wave-instructions per env (one SQ pass: SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_LDS)"""
+    names = ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
+    cols = [series(d, c) for c in names]
+    prev = [0.0] * len(names)
+    print("%-34s %10s %10s %10s %10s   (wave-instructions per env)" % ("phase", "vmem rd", "vmem wr", "valu", "lds"))
+    for i, st in enumerate(STOPS):
+        cur = [c[i] / E for c in cols]
+        if st == 0:
+            print("%-34s " % "whole step" + " ".join("%10.0f" % v for v in cur))
+            continue
+        half, ph = divmod(st - 1, 8)
+        print("%-34s " % ("half %d %s" % (half, NAMES[ph])) + " ".join("%10.0f" % (a - b) for a, b in zip(cur, prev)))
+        prev = cur
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "insts":
+        report_insts(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3])
