@@ -1,0 +1,130 @@
+"""TF-free agent process: the XML-RPC service of the reference's `server/server.py` (same eight
+methods, argument/return types and number formatting) with the PyTorch TD3 of `td3.py` inside.
+
+    python -m rlfluidcontrol_amd.learner_server -env CFD -fil None -exn Gaussian
+
+Either side of the reference's wire protocol can now be replaced independently: an unchanged
+Processing sketch (`clientLilypad/clientCFD.pde`) can talk to this server, and
+`driver_rpc.LilypadRPCDriver` can talk to an unchanged `server.py`.  The
+"Experiment" environment (load-cell calibration, server.py:67-90) is lab hardware and out of scope.
+"""
+import argparse
+import os
+import threading
+from xmlrpc.server import SimpleXMLRPCServer
+
+import numpy as np
+import torch
+
+from . import td3
+
+
+class LearnerServer:
+    METHODS = ("init", "start_episode", "request_stochastic_action", "request_deterministic_action", "train", "save",
+               "save_eval", "restore")
+
+    def __init__(self, environment="CFD", filter="None", explore_noise="Gaussian", one_action=False, host="localhost",
+                 port=8000, device="cpu", seed=None, save_dir="save", data_dir="save_data", eval_dir="save_eval"):
+        if environment != "CFD":
+            raise NotImplementedError("only the CFD environment (server.py:117-118) is served")
+        self.learner = td3.BatchedLearner(1, device=device, filter=filter, explore_noise=explore_noise,
+                                          one_action=one_action, seed=seed)
+        self.unfiltered_state_record = []
+        self.save_model_dir, self.save_data_dir, self.save_eval_dir = save_dir, data_dir, eval_dir
+        self.server = SimpleXMLRPCServer((host, port), logRequests=False, allow_none=True)
+        self.port = self.server.server_address[1]
+        for name in self.METHODS:  # server.py:51-59
+            self.server.register_function(getattr(self, "_" + name), name)
+        self.thread = None
+
+    # -- lifetime --
+    def start_server(self):
+        self.server.serve_forever()
+
+    def start(self):
+        self.thread = threading.Thread(target=self.server.serve_forever, daemon=True)
+        self.thread.start()
+        return self
+
+    def stop(self):
+        self.server.shutdown()
+        self.server.server_close()
+
+    @property
+    def agent(self):
+        return self.learner.agent
+
+    # -- the eight methods --
+    def _init(self, episode_count):  # server.py:92-100
+        try:
+            self._restore(episode_count)
+            return True
+        except Exception:
+            self.agent.reset_agent()
+            return False
+
+    def _start_episode(self, raw_data):  # server.py:102-112
+        self.unfiltered_state_record = []
+        self.learner.start_episode()
+        return True
+
+    def _request_action(self, raw_data, stochastic):  # server.py:114-140
+        state = np.array([float(x) for x in raw_data.split("_")], dtype=np.float64)[None, :]
+        obs = torch.as_tensor(state, dtype=torch.float32, device=self.agent.device)
+        action = self.learner.request_action(obs, stochastic=stochastic)
+        self.unfiltered_state_record.append(state)
+        a = action[0].detach().cpu().numpy()
+        # the reference returns str() of numpy scalars: float64 after exploration noise, float32 otherwise
+        vals = [np.float64(x) for x in a] if stochastic else [np.float32(x) for x in a]
+        return "_".join(str(v) for v in vals)
+
+    def _request_stochastic_action(self, raw_data):
+        return self._request_action(raw_data, True)
+
+    def _request_deterministic_action(self, raw_data):
+        return self._request_action(raw_data, False)
+
+    def _records(self):
+        st = np.array([s.cpu().numpy() for s in self.learner.state_record])
+        ac = np.array([a.cpu().numpy() for a in self.learner.action_record])
+        return dict(state=st, unfiltered_state=np.array(self.unfiltered_state_record), action=ac)
+
+    def _train(self, steps):  # server.py:148-170
+        os.makedirs(self.save_data_dir, exist_ok=True)
+        np.savez(os.path.join(self.save_data_dir, "data_{}.npz".format(self.agent.episode_count)), **self._records())
+        self.learner.train(int(steps))
+        return True
+
+    def _save_eval(self, episode_count, rep_count):  # server.py:172-179
+        os.makedirs(self.save_eval_dir, exist_ok=True)
+        np.savez(os.path.join(self.save_eval_dir, "data_{}_{}.npz".format(episode_count, rep_count)), **self._records())
+        return True
+
+    def _save(self, dummy=None):  # server.py:181-190 (TF checkpoint + pickled buffer -> one torch file)
+        os.makedirs(self.save_model_dir, exist_ok=True)
+        torch.save(self.agent.state_dict(), os.path.join(self.save_model_dir, "{}.pt".format(self.agent.episode_count)))
+        return True
+
+    def _restore(self, episode_count):  # server.py:192-198
+        sd = torch.load(os.path.join(self.save_model_dir, "{}.pt".format(episode_count)), map_location=self.agent.device,
+                        weights_only=False)
+        self.agent.load_state_dict(sd)
+        self.agent.episode_count = episode_count
+        return True
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="TD3 learner serving the Lilypad XML-RPC protocol")
+    ap.add_argument("-env", "--environment", choices=["CFD"], default="CFD")
+    ap.add_argument("-fil", "--filter", choices=["None", "Kalman"], default="Kalman")
+    ap.add_argument("-exn", "--explore_noise", choices=["Gaussian", "Process"], default="Gaussian")
+    ap.add_argument("-one", "--one_action", action="store_true")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--device", default="cuda:0" if torch.cuda.is_available() else "cpu")
+    a = ap.parse_args(argv)
+    LearnerServer(environment=a.environment, filter=a.filter, explore_noise=a.explore_noise, one_action=a.one_action,
+                  port=a.port, device=a.device).start_server()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""TD3 in the loop with the batched HIP environment (BASELINE.json cfg5).
+
+The reference trains one env through XML-RPC: 408 requests per episode, then `train(1000)`
+(clientCFD.pde:35-85, server.py:148-170).  Here E envs of one GPU run the same episode protocol
+in lock-step and the learner lives on the same device: observations, actions, records and the
+replay buffer never leave HBM; at the end of an episode the E x 407 transitions are stored and
+`train_steps` TD3 iterations run.
+
+    python -m rlfluidcontrol_amd.train --envs 1024 --episodes 2 --train-steps 1000
+
+Multi-GPU: launch one process per GPU (torchrun); every rank steps its shard, the one all-gather
+per agent step of `ShardedVecEnv` gives every rank the global observation, and the learner is
+REPLICATED (same seed, same inputs => same weights and actions on every rank), so no gradient
+collective is needed for a 0.2 M-parameter model.
+"""
+import argparse
+import json
+import time
+
+import torch
+
+from . import td3
+from .vec_env import HipBackend, ShardedVecEnv
+
+
+def run_episode(vec, learner, max_requests=None, stochastic=True):
+    """One pass of the reference's draw() loop for all envs: returns (requests, mean reward per request)."""
+    W, E = vec.world, vec.E
+    action = torch.zeros(W * E, 2, device=vec.device)
+    learner.start_episode()
+    n, rew_sum = 0, 0.0
+    while True:
+        obs, rew, done = vec.step(action)
+        if bool(done.all()):  # the window running when t reached Time never completes (clientCFD.pde:36)
+            break
+        action = learner.request_action(obs, stochastic=stochastic)
+        if n > 0:
+            rew_sum += float(rew.mean())
+        n += 1
+        if max_requests is not None and n >= max_requests:
+            break
+    return n, rew_sum / max(n - 1, 1)
+
+
+def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=1000, device="cuda:0", seed=0,
+          filter="None", explore_noise="Gaussian", init=None, max_requests=None, env_kwargs=None, batch_size=None,
+          log=print):
+    from . import build, env as envmod
+    build.build()
+    dev = torch.device(device)
+    torch.cuda.set_device(dev)
+    g = envmod.AFCEnv(num_envs=num_envs, resolution=resolution, reynolds=reynolds, device=dev.index or 0,
+                      **(env_kwargs or {}))
+    if init is not None:
+        g.set_reset_state(init["u"], init["v"], init["p"])
+    vec = ShardedVecEnv(HipBackend(g, dev), num_envs, device=dev)
+    learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed)
+    if batch_size:
+        learner.agent.bs = batch_size
+    history = []
+    for ep in range(episodes):
+        g.reset()
+        t0 = time.time()
+        n, mean_r = run_episode(vec, learner, max_requests=max_requests)
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        learner.train(train_steps)
+        torch.cuda.synchronize(dev)
+        t2 = time.time()
+        rec = dict(episode=ep + 1, requests=n, mean_reward=mean_r, rollout_s=t1 - t0, train_s=t2 - t1,
+                   buffer=learner.agent.replay_buffer.size, td3_iters=learner.agent.total_step_count)
+        history.append(rec)
+        log(json.dumps(rec))
+    g.close()
+    return learner, history
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--res", type=int, default=16)
+    ap.add_argument("--reynolds", type=int, default=100)
+    ap.add_argument("--episodes", type=int, default=1)
+    ap.add_argument("--train-steps", type=int, default=1000)
+    ap.add_argument("--max-requests", type=int, default=None)
+    ap.add_argument("--filter", choices=["None", "Kalman"], default="None")
+    ap.add_argument("--explore-noise", choices=["Gaussian", "Process"], default="Gaussian")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    train(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, episodes=a.episodes, train_steps=a.train_steps,
+          max_requests=a.max_requests, filter=a.filter, explore_noise=a.explore_noise, seed=a.seed)
+
+
+if __name__ == "__main__":
+    main()

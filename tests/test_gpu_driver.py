@@ -93,3 +93,24 @@ def test_developed_wake_fixture_is_a_fixed_point_class(envmod):
     assert min(cls) < -0.05 and max(cls) > 0.05
     assert 1.0 < float(obs[0, 1]) < 2.5
     g.close()
+
+
+def test_td3_in_the_loop_on_device(envmod):
+    """cfg5 plumbing: E envs + the TD3 learner on one GPU, two short episodes; records, transitions and
+    training all stay on the device; rewards are the reference's formula applied to the recorded obs."""
+    import torch
+
+    from rlfluidcontrol_amd import td3, train
+
+    learner, hist = train.train(num_envs=8, resolution=8, reynolds=100, episodes=2, train_steps=4, seed=1, batch_size=16,
+                                env_kwargs=dict(init_time=0.05, end_time=0.62), log=lambda s: None)
+    assert [h["requests"] for h in hist] == [4, 4]  # same float32 bookkeeping as the single-env driver test
+    ag = learner.agent
+    assert ag.replay_buffer.size == 2 * 3 * 8 and ag.total_step_count == 8 and ag.episode_count == 2
+    assert ag.replay_buffer.obs1_buf.is_cuda
+    n = ag.replay_buffer.size
+    s2, a, r = ag.replay_buffer.obs2_buf[:n], ag.replay_buffer.acts_buf[:n], ag.replay_buffer.rews_buf[:n, 0]
+    assert torch.allclose(r, td3.reward_func(s2, a), atol=1e-6)
+    assert float(a.abs().max()) <= 1.0 and torch.isfinite(s2).all()
+    # envs received different exploration noise, so their wakes (observations) differ
+    assert float(ag.replay_buffer.obs2_buf[n - 8:n, 1].std()) > 0
