@@ -52,6 +52,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:  # PyTorch ships its own HIP runtime under the same SONAME: when both live in one process
+        import torch  # noqa: F401  (torch's copy must be the one the loader binds first)
+    except ImportError:
+        pass
     path = os.environ.get("AFC_ENV_LIB", LIB_PATH)  # override: A/B runs of two builds on one GPU box
     if not os.path.exists(path):
         raise AfcError("libafc_env.so is missing: build it with `python -m rlfluidcontrol_amd.build` "

@@ -114,3 +114,27 @@ def test_td3_in_the_loop_on_device(envmod):
     assert float(a.abs().max()) <= 1.0 and torch.isfinite(s2).all()
     # envs received different exploration noise, so their wakes (observations) differ
     assert float(ag.replay_buffer.obs2_buf[n - 8:n, 1].std()) > 0
+
+
+def test_savescalar_log_and_vorticity_picture_from_the_env(envmod, tmp_path):
+    """the sketch's per-frame log line and its picture, produced from the GPU env and checked against the oracle"""
+    from oracle.oracle_py import Oracle
+    from rlfluidcontrol_amd import logs
+
+    g = envmod.AFCEnv(num_envs=2, resolution=8, reynolds=100, exact_sums=1)
+    o = Oracle(resolution=8, Re=100)
+    lg = logs.SaveScalarLog(str(tmp_path / "1.txt"))
+    logs.record_run(g, lg, 3, xi=(0.5, -0.25))
+    lg.finish()
+    rows = [l.split() for l in (tmp_path / "1.txt").read_text().split("\n")[4:] if l]
+    assert len(rows) == 3
+    for k, toks in enumerate(rows):
+        fo, _, _ = o.update2(2.5, -1.25)  # xi_m = 5 * xi (clientCFD.pde:53-54)
+        assert len(toks) == 37
+        assert np.float32(toks[0]) == np.float32(o.t)
+        assert np.float32(toks[1]) == fo[0] and np.float32(toks[2]) == fo[1]
+        assert (toks[3], toks[4]) == ("0.5", "-0.25")
+        assert np.array_equal(np.array(toks[5:], np.float32), o.probes(32))
+    h, w = logs.vorticity_png(str(tmp_path / "result.png"), g.vorticity(0), zoom=3)
+    assert (h, w) == (3 * g.m, 3 * g.n) and (tmp_path / "result.png").stat().st_size > 200
+    g.close()
