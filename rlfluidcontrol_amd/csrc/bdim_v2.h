@@ -17,6 +17,34 @@ namespace afc {
 // keep __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Values that are the same in every lane but reached the wave through vector loads (the level
+// table sits in global memory) occupy a VGPR each and get spilled around the register-hungry
+// loops; readfirstlane moves them to SGPRs.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T *uni(T *p) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Lv uni(const Lv &L) {
+  Lv U;
+  U.n = uni(L.n);
+  U.m = uni(L.m);
+  U.lx = uni(L.lx);
+  U.ly = uni(L.ly);
+  U.inv = uni(L.inv);
+  U.r = uni(L.r);
+  U.x = uni(L.x);
+  U.d = uni(L.d);
+  U.desc = uni(L.desc);
+  return U;
+}
+
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
 // flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
@@ -1023,7 +1051,7 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
   while (iter < P.mg_max_iters) {
     ++iter;
     for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
-      const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
       if (l == 0 && iter == 1 && fused_head) {
         mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
       } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
@@ -1045,14 +1073,14 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     }
     float rr = 0.f;
     {
-      const Lv Lk = make_level(P, e, kc);  // coarsest: coarse.smooth(its), MG.pde:73
+      const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
       mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
     }
     for (int l = kc - 1; l >= 0; --l) {
       if (l == 0 && pf.stop == 4) return iter;
-      const Lv F = (l == 0) ? L0 : make_level(P, e, l), Cc = make_level(P, e, l + 1);
+      const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(P.dbg & 2);
