@@ -97,14 +97,14 @@ template <int C>
 __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
                                  float *__restrict__ dy, float *lds) {
-  const int n = P.n, m = P.m, N = P.N;
-  const int R = P.adv_rows, TR = R + 4;
+  const int n = uni(P.n), m = uni(P.m), N = uni(P.N);
+  const int R = uni(P.adv_rows), TR = R + 4;
   float *tx = lds + 2, *ty = lds + 2 + TR * m + 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int RW = R >> 2;
   const int j0 = 1 + C * lane;
   const bool lane_on = (j0 <= m - 2);
-  const float nu = P.nu, dt = P.dt;
+  const float nu = uni(P.nu), dt = uni(P.dt);
   const bool same = (bx == sx) && (by == sy);
   for (int a = 1; a <= n - 2; a += R) {
     // ---- stage rows a-2 .. a+R+1 of src into LDS (flat, coalesced float2) ----
@@ -1204,9 +1204,10 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
   const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
-  float *Ax = G(P.ux) + eo, *Ay = G(P.uy) + eo, *Bx = G(P.usx) + eo, *By = G(P.usy) + eo, *Cx = G(P.fx) + eo, *Cy = G(P.fy) + eo;
-  float *scratch = G(P.u0x) + eo;
-  float *p0 = G(P.p) + eo, *p1 = G(P.d) + eo;  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
+  float *Ax = uni(G(P.ux) + eo), *Ay = uni(G(P.uy) + eo), *Bx = uni(G(P.usx) + eo), *By = uni(G(P.usy) + eo),
+        *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo);
+  float *scratch = uni(G(P.u0x) + eo);
+  float *p0 = uni(G(P.p) + eo), *p1 = uni(G(P.d) + eo);  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
   float shift = *pshift;
   Prof pf;
@@ -1218,10 +1219,10 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   float lin[2] = {0.f, 0.f};
 #pragma nounroll
   for (int half = 0; half < 2; ++half) {
-    const float *sx = half ? Bx : Ax, *sy = half ? By : Ay;
-    float *dx = half ? Cx : Bx, *dy = half ? Cy : By;
-    const float *pin = half ? p1 : p0;
-    float *pout = half ? p0 : p1;
+    const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
+    float *dx = uni(half ? Cx : Bx), *dy = uni(half ? Cy : By);
+    const float *pin = uni(half ? p1 : p0);
+    float *pout = uni(half ? p0 : p1);
     advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
     pf.mark(PF_ADVDIF);
     if (pf.stop == 1 + 8 * half) return;
