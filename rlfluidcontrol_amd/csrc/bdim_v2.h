@@ -44,6 +44,19 @@ __device__ __forceinline__ Lv uni(const Lv &L) {
   U.desc = uni(L.desc);
   return U;
 }
+struct DescU {  // the scalar fields of a LevelDesc, in SGPRs
+  float cu, iv0;
+  int zb, sp_i0, sp_i1;
+};
+__device__ __forceinline__ DescU desc_u(const LevelDesc &D) {
+  DescU u;
+  u.cu = uni(D.cu);
+  u.iv0 = uni(D.invtab[0]);
+  u.zb = uni(D.zero_bnd);
+  u.sp_i0 = uni(D.sp_i0);
+  u.sp_i1 = uni(D.sp_i1);
+  return u;
+}
 
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
@@ -295,18 +308,18 @@ __device__ __host__ __forceinline__ int gs_lds_floats(int m) {
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
-__device__ __forceinline__ void coef_analytic(const LevelDesc &D, int i, int j, int n_, int m_, float &lw, float &le,
-                                              float &ls, float &ln, float &iv) {
-  if (!D.zero_bnd) {  // finest level: boundary faces keep c = dt, inv is the same everywhere
-    lw = le = ls = ln = D.cu;
-    iv = D.invtab[0];
+__device__ __forceinline__ void coef_analytic(const LevelDesc &D, const DescU &du, int i, int j, int n_, int m_,
+                                              float &lw, float &le, float &ls, float &ln, float &iv) {
+  if (!du.zb) {  // finest level: boundary faces keep c = dt, inv is the same everywhere
+    lw = le = ls = ln = du.cu;
+    iv = du.iv0;
     return;
   }
   const float b = 0.f;
-  lw = (i == 1) ? b : D.cu;
-  le = (i == n_) ? b : D.cu;
-  ls = (j == 1) ? b : D.cu;
-  ln = (j == m_) ? b : D.cu;
+  lw = (i == 1) ? b : du.cu;
+  le = (i == n_) ? b : du.cu;
+  ls = (j == 1) ? b : du.cu;
+  ln = (j == m_) ? b : du.cu;
   iv = D.invtab[3 * ((i == 1) ? 1 : ((i == n_) ? 2 : 0)) + ((j == 1) ? 1 : ((j == m_) ? 2 : 0))];
 }
 
@@ -335,8 +348,8 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
     iv1 = D.invtab[3 * rc + 1];
     iv2 = D.invtab[3 * rc + 2];
   }
-  const float cu = D.cu;
-  const bool zb = ZB && D.zero_bnd != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
+  const float cu = uni(D.cu);
+  const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
   const int steps = (m_ + 18 + 3) & ~3;  // multiple of 4 (the extra steps are inactive)
   const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
   // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k).  Operands of
@@ -457,6 +470,7 @@ struct UpGeom {
   const LevelDesc *D;
   int n, m, n_, m_, mc, PW, CPR;
   float *rr, *dr;
+  DescU du;
   bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
   bool update_x = true;  // false: replay that only materialises r
 };
@@ -514,7 +528,7 @@ __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int
       float a0, a1, a2, a3;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        coef_analytic(*U.D, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
+        coef_analytic(*U.D, U.du, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
         lw.v[e] = a0;
         le.v[e] = a1;
         ls.v[e] = a2;
@@ -601,7 +615,7 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
       float a0, a1, a2, a3, a4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        coef_analytic(*U.D, g, j + e, n_, m_, a0, a1, a2, a3, a4);
+        coef_analytic(*U.D, U.du, g, j + e, n_, m_, a0, a1, a2, a3, a4);
         lw.v[e] = a0;
         le.v[e] = a1;
         ls.v[e] = a2;
@@ -688,7 +702,8 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   float linf = 0.f;
   const int CPR = m_ >> 2;
   const bool chunked = ((m_ & 3) == 0);
-  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr};
+  const DescU du = desc_u(D);
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
   __syncthreads();
@@ -700,7 +715,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
     // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
     const int hi = I0 + 16;
-    const bool sp_fill = (hi + 1 >= D.sp_i0) && (loaded <= D.sp_i1);
+    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
     if (chunked) {
       // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
       const int nrow = hi - loaded;
@@ -725,7 +740,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
             ln = F.ly[kk + 1];
             iv = F.inv[kk];
           } else {
-            coef_analytic(D, g, j, n_, m_, lw, le, ls, ln, iv);
+            coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
           }
           if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
             const float dc = prolong_at(Cc.x, mc, g, j, n_, m_);
@@ -751,11 +766,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     lds_barrier();
     if (need_r) pf.mark(PF_UP0);
     if (tid < 64) {
-      const bool special = (I0 + 16 >= D.sp_i0) && (I0 - 3 <= D.sp_i1);
+      const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
         gs_march<false>(F, rr, dr, carry, zrow, dummy, I0);
-      else if (D.zero_bnd)
+      else if (du.zb)
         gs_march<true, true>(F, rr, dr, carry, zrow, dummy, I0);
       else
         gs_march<true, false>(F, rr, dr, carry, zrow, dummy, I0);
@@ -765,7 +780,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (need_r) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
-    const bool sp_exit = (e1 + 1 >= D.sp_i0) && (e0 - 1 <= D.sp_i1);
+    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
     if (chunked) {
       const int nrow = e1 - e0 + 1;
       for (int q = tid; q < nrow * CPR; q += kThreads) {
@@ -793,7 +808,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
               ls = F.ly[kk];
               ln = F.ly[kk + 1];
             } else {
-              coef_analytic(D, g, j, n_, m_, lw, le, ls, ln, iv);
+              coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
             }
             const float diag = -(lw + le + ls + ln);
             const float rn = rr[sl + j] - (d * diag + dW * lw + dE * le + dS * ls + dN * ln);  // MG.pde:96
@@ -874,7 +889,8 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   float *t0 = lds + 8;  // r0 tile: 16 rows, pitch m
   const int tid = threadIdx.x;
   const int m1 = L1.m;
-  const bool uni = (D.zero_bnd == 0);  // finest level: all coefficients uniform outside the special rows
+  const DescU du = desc_u(D);
+  const bool unif = (du.zb == 0);  // finest level: all coefficients uniform outside the special rows
   // rows per block: 14 on the finest grids; on narrow (coarse) levels enough rows to give every
   // thread a patch (7*k*CPR patches per block), bounded by the 2080-float tile
   int kblk = 1;
@@ -885,7 +901,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   }
   const int R = 14 * kblk, TR = R + 2, NPAIR = 7 * kblk;
   for (int a = 1; a <= n_; a += R) {
-    const bool sp = (a + R + 1 >= D.sp_i0) && (a - 2 <= D.sp_i1);
+    const bool sp = (a + R + 1 >= du.sp_i0) && (a - 2 <= du.sp_i1);
     lds_barrier();
     // ---- step 1: r0 for rows a-1 .. a+R ----
     for (int q = tid; q < TR * CPR; q += kThreads) {
@@ -909,8 +925,8 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
           ln4 = L0.ly[k + 4];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
-          ln4 = D.cu;
+          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+          ln4 = du.cu;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -950,8 +966,8 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
           float iv;
           if (sp) {
             iv = L0.inv[gg * m + jj];
-          } else if (uni) {
-            iv = D.invtab[0];
+          } else if (unif) {
+            iv = du.iv0;
           } else {
             iv = D.invtab[3 * ((gg == 1) ? 1 : ((gg == n_) ? 2 : 0)) + ((jj == 1) ? 1 : ((jj == m_) ? 2 : 0))];
           }
@@ -969,15 +985,15 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
           le = load4u(L0.lx + k + m);
           ls = load4u(L0.ly + k);
           ln4 = L0.ly[k + 4];
-        } else if (uni) {
+        } else if (unif) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = D.cu;
-          ln4 = D.cu;
+          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+          ln4 = du.cu;
         } else {
           float a0, a1, a2, a3, a4v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            coef_analytic(D, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
+            coef_analytic(D, du, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
             lw.v[e] = a0;
             le.v[e] = a1;
             ls.v[e] = a2;
@@ -1108,9 +1124,10 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
                                        float shift, float *vx,
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
                                        float *ax, float *ay) {
-  const int n = P.n, m = P.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
-  const int sp0 = P.lev[0].sp_i0, sp1 = P.lev[0].sp_i1;
-  const float cu = P.lev[0].cu;
+  const int n = uni(P.n), m = uni(P.m), n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  const int sp0 = uni(P.lev[0].sp_i0), sp1 = uni(P.lev[0].sp_i1);
+  const float cu = uni(P.lev[0].cu);
+  const float *pcx = uni(G(P.cx)), *pcy = uni(G(P.cy));
   // a thread walks down one 4-column chunk through its group's rows, so the row above (p west of
   // the x-faces) is the chunk it read one iteration earlier and p crosses HBM once
   const int ngrp = kThreads / CPR, rg = threadIdx.x / CPR, c4 = threadIdx.x - rg * CPR;
@@ -1127,8 +1144,8 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
     const F4 u4 = load4u(vx + k), v4 = load4u(vy + k);
     F4 cx4, cy4;
     if (g >= sp0 && g <= sp1) {  // rows that cross a body: the real coefficient arrays
-      cx4 = load4u(G(P.cx) + k);
-      cy4 = load4u(G(P.cy) + k);
+      cx4 = load4u(pcx + k);
+      cy4 = load4u(pcy + k);
     } else {  // verified on the host: every face coefficient of the row equals cu (LevelDesc)
 #pragma unroll
       for (int e = 0; e < 4; ++e) cx4.v[e] = cy4.v[e] = cu;
