@@ -98,50 +98,62 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
   }
-  EnvScalars s = G(P.sc)[e];  // every thread keeps an identical private copy (uniform control flow)
+  // the env's episode scalars live in LDS for the whole launch (thread 0 does the bookkeeping of
+  // clientCFD.pde:35-56, everybody reads what the control flow needs): no per-thread register copies
+  __shared__ EnvScalars s;
+  __shared__ int s_stop;
   const float a1 = action[2 * e], a2 = action[2 * e + 1];
-  s.xi1 = a1;  // clientCFD.pde:51-54
-  s.xi2 = a2;
-  s.xi1_m = P.act_scale * s.xi1;
-  s.xi2_m = P.act_scale * s.xi2;
+  if (threadIdx.x == 0) {
+    s = G(P.sc)[e];
+    s.xi1 = a1;  // clientCFD.pde:51-54
+    s.xi2 = a2;
+    s.xi1_m = P.act_scale * s.xi1;
+    s.xi2_m = P.act_scale * s.xi2;
+    s_stop = 0;
+  }
+  __syncthreads();
+  const float xi1_m = afc::uni(s.xi1_m), xi2_m = afc::uni(s.xi2_m);
+  float pshift = s.p_shift;
   int steps = 0;
-  bool got = false;
   long long dbg_t0 = 0;
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
     if ((P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
-    step_dispatch<CPL>(P, e, s.xi1_m, s.xi2_m, &s.p_shift, sm, &sh, lds_dyn);
+    step_dispatch<CPL>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
     ++steps;
-    s.t += P.dt / P.resolution;
-    s.force_x = sh.fx;
-    s.force_y = sh.fy;
-    s.iters[0] = sh.it0;
-    s.iters[1] = sh.it1;
-    s.resid[0] = sh.r0;
-    s.resid[1] = sh.r1;
-    s.sim_steps += 1;
-    if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
-    if (s.t > P.init_time) {  // clientCFD.pde:39-47
-      s.callLearn--;
-      s.Cd += sh.fx;
-      s.Cl += sh.fy;
-      if (s.callLearn <= 0) {
-        s.callLearn = P.substeps;
-        s.Cd = s.Cd / s.callLearn * 2 / P.resolution;
-        s.Cl = s.Cl / s.callLearn * 2 / P.resolution;
-        s.obs_cl = s.Cl;
-        s.obs_cd = s.Cd;
-        if (!P.carry_quirk) {
-          s.Cd = 0.f;
-          s.Cl = 0.f;
+    if (threadIdx.x == 0) {
+      s.t += P.dt / P.resolution;
+      s.force_x = sh.fx;
+      s.force_y = sh.fy;
+      s.iters[0] = sh.it0;
+      s.iters[1] = sh.it1;
+      s.resid[0] = sh.r0;
+      s.resid[1] = sh.r1;
+      s.sim_steps += 1;
+      if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
+      if (s.t > P.init_time) {  // clientCFD.pde:39-47
+        s.callLearn--;
+        s.Cd += sh.fx;
+        s.Cl += sh.fy;
+        if (s.callLearn <= 0) {
+          s.callLearn = P.substeps;
+          s.Cd = s.Cd / s.callLearn * 2 / P.resolution;
+          s.Cl = s.Cl / s.callLearn * 2 / P.resolution;
+          s.obs_cl = s.Cl;
+          s.obs_cd = s.Cd;
+          if (!P.carry_quirk) {
+            s.Cd = 0.f;
+            s.Cl = 0.f;
+          }
+          s_stop = 1;
         }
-        got = true;
-        break;
       }
     }
     __syncthreads();
+    if (s_stop) break;
   }
   if (threadIdx.x == 0) {
+    s.p_shift = pshift;
     G(P.sc)[e] = s;
     obs[2 * e] = s.obs_cl;  // wire order is Cl then Cd (clientCFD.pde:120)
     obs[2 * e + 1] = s.obs_cd;
@@ -153,7 +165,6 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
       obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
       obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
     }
-    (void)got;
   }
 }
 
