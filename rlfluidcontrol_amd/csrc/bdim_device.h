@@ -113,18 +113,25 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // ---- optional phase profiling (env 0, thread 0; ticks of wall_clock64 = 100 MHz) ----
 struct Prof {
-  long long *acc;
-  long long last;
-  int stop = 0;  // diagnostic: leave the step after phase `stop` (per-phase HBM traffic by differencing)
+  long long *acc;  // same in every lane (null unless this is workgroup 0 of a profiled launch): SGPRs
+  int stop = 0;    // diagnostic: leave the step after phase `stop` (per-phase HBM traffic by differencing)
+  __device__ __forceinline__ long long &last_stamp() {
+    __shared__ long long s_last;  // time of the previous mark (thread 0 only)
+    return s_last;
+  }
   __device__ void start(const StepParams &P) {
-    acc = (G(P.stamps) && blockIdx.x == 0 && threadIdx.x == 0) ? G(P.stamps) : nullptr;
-    if (acc) last = wall_clock64();
+    long long *a = (blockIdx.x == 0) ? G(P.stamps) : nullptr;
+    const unsigned long long v = reinterpret_cast<unsigned long long>(a);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    acc = reinterpret_cast<long long *>(((unsigned long long)hi << 32) | lo);
+    if (acc && threadIdx.x == 0) last_stamp() = wall_clock64();
   }
   __device__ __forceinline__ void mark(int id) {
-    if (acc) {
+    if (acc && threadIdx.x == 0) {
       const long long now = wall_clock64();
-      acc[id] += now - last;
-      last = now;
+      acc[id] += now - last_stamp();
+      last_stamp() = now;
     }
   }
 };

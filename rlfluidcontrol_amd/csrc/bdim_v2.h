@@ -1229,7 +1229,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   float shift = *pshift;
   Prof pf;
   pf.start(P);
-  pf.stop = (P.dbg >> 12) & 15;
+  pf.stop = uni((P.dbg >> 12) & 15);
   // half 0 = predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP                    -> B
   // half 1 = corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; (u+us)/2 -> C, A
   int its[2] = {0, 0};
