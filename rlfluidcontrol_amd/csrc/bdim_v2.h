@@ -856,9 +856,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   }
   __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
   if (need_r && rmode != 2) {
-    *rr_out = (float)block_sum_d(rr_part, sm);
-    *linf_out = block_max_f(linf, sm);
-    if (xsum_out) *xsum_out = (float)block_sum_d(xs_part, sm);
+    *rr_out = uni((float)block_sum_d(rr_part, sm));
+    *linf_out = uni(block_max_f(linf, sm));
+    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
   }
 }
 
@@ -886,6 +886,7 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
     pin = L0.x;
     shift = 0.f;
   }
+  shift = uni(shift);
   float *t0 = lds + 8;  // r0 tile: 16 rows, pitch m
   const int tid = threadIdx.x;
   const int m1 = L1.m;
@@ -1208,7 +1209,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   if (pf.stop >= 3 && pf.stop <= 5) return iters;
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
-  const float shift = -1 * psum / (float)((P.n - 2) * (P.m - 2));  // VectorField.pde:136
+  const float shift = uni(-1 * psum / (float)((P.n - 2) * (P.m - 2)));  // VectorField.pde:136
   project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay);
   *shift_io = shift;
   pf.mark(PF_PROJECT);
@@ -1219,14 +1220,14 @@ template <int C>
 __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
                                    ShBcast *sh, float *lds) {
   const size_t eo = e * (size_t)P.Ns;
-  const float dphi1 = (2 * xi1_m * P.dt) / (P.dR * P.D);  // AFCCylinder.pde:48-49
-  const float dphi2 = (2 * xi2_m * P.dt) / (P.dR * P.D);
+  const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
+  const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
   float *Ax = uni(G(P.ux) + eo), *Ay = uni(G(P.uy) + eo), *Bx = uni(G(P.usx) + eo), *By = uni(G(P.usy) + eo),
         *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo);
   float *scratch = uni(G(P.u0x) + eo);
   float *p0 = uni(G(P.p) + eo), *p1 = uni(G(P.d) + eo);  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
-  float shift = *pshift;
+  float shift = uni(*pshift);
   Prof pf;
   pf.start(P);
   pf.stop = uni((P.dbg >> 12) & 15);
