@@ -1162,7 +1162,7 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
     }
     store4u(vx + k, un);
     store4u(vy + k, vn);
-    if (HEUN) {  // cells on the lines setBC rewrites are redone below
+    if (HEUN) {  // cells on the rows setBC rewrites (0, 1, n-2, n-1) are redone below
       const F4 b4 = load4u(ox + k), d4 = load4u(oy + k);
       F4 a4, e4;
 #pragma unroll
@@ -1170,22 +1170,27 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
         a4.v[e] = (un.v[e] + b4.v[e]) * 0.5f;
         e4.v[e] = (vn.v[e] + d4.v[e]) * 0.5f;
       }
+      // wall columns: the average uses what setBC is about to put there (Field.pde:217-224):
+      // u.x mirrors the adjacent interior cell, u.y[.][0] = old u.y[.][1], u.y[.][1] = u.y[.][m-1] = 0
+      if (c4 == 0) {
+        ax[k - 1] = (un.v[0] + ox[k - 1]) * 0.5f;
+        ay[k - 1] = (vn.v[0] + oy[k - 1]) * 0.5f;
+        e4.v[0] = (0.f + d4.v[0]) * 0.5f;
+      }
+      if (c4 == CPR - 1) {
+        ax[k + 4] = (un.v[3] + ox[k + 4]) * 0.5f;
+        ay[k + 4] = (0.f + oy[k + 4]) * 0.5f;
+      }
       store4u(ax + k, a4);
       store4u(ay + k, e4);
     }
   }
   __syncthreads();
   setbc_vel(P, vx, vy, lds);
-  if (HEUN) {  // lines touched by setBC: rows 0,1,n-1 and columns 0,1,m-1
-    for (int q = threadIdx.x; q < 3 * m + 3 * n; q += kThreads) {
-      int k;
-      if (q < 3 * m) {
-        const int rsel = q / m, j = q - rsel * m;
-        k = ((rsel == 0) ? 0 : ((rsel == 1) ? 1 : (n - 1))) * m + j;
-      } else {
-        const int qq = q - 3 * m, csel = qq / n, i = qq - csel * n;
-        k = i * m + ((csel == 0) ? 0 : ((csel == 1) ? 1 : (m - 1)));
-      }
+  if (HEUN) {  // whole rows touched by setBC's row part or by its mean correction: 0, 1, n-2, n-1
+    for (int q = threadIdx.x; q < 4 * m; q += kThreads) {
+      const int rsel = q / m, j = q - rsel * m;
+      const int k = ((rsel < 2) ? rsel : (n - 4 + rsel)) * m + j;
       ax[k] = (vx[k] + ox[k]) * 0.5f;
       ay[k] = (vy[k] + oy[k]) * 0.5f;
     }
