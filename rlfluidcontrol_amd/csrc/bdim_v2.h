@@ -495,12 +495,14 @@ __device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, in
       const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
       const float *xw = U.Cc->x + ((gw - 1) / 2 + 1) * U.mc + 2 * c4;
       const float *xe = U.Cc->x + ((ge - 1) / 2 + 1) * U.mc + 2 * c4;
+      // three 16-byte loads instead of eight dwords
+      const F4 va = load4u(xa), vw = load4u(xw), ve = load4u(xe);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) in.a[e] = xa[e];
-      in.w1 = xw[1];
-      in.w2 = xw[2];
-      in.e1 = xe[1];
-      in.e2 = xe[2];
+      for (int e = 0; e < 4; ++e) in.a[e] = va.v[e];
+      in.w1 = vw.v[1];
+      in.w2 = vw.v[2];
+      in.e1 = ve.v[1];
+      in.e2 = ve.v[2];
     }
   }
   return in;
@@ -572,8 +574,10 @@ __device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, in
   in.x = load4u(U.F->x + kk);
   if (HASC) {
     const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
-    in.a1 = xa[1];
-    in.a2 = xa[2];
+    float a12[2];
+    __builtin_memcpy(a12, xa + 1, 8);  // one 8-byte load
+    in.a1 = a12[0];
+    in.a2 = a12[1];
   }
   if (c4 == 0) in.gl = U.F->x[kk - 1];
   if (c4 == U.CPR - 1) in.gh = U.F->x[kk + 4];
