@@ -25,11 +25,12 @@ __device__ __forceinline__ float uni(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 template <class T>
-__device__ __forceinline__ T *uni(T *p) {
+__device__ __forceinline__ T *uni(T *p) {  // p points to GLOBAL memory (all our field / table pointers do)
   const unsigned long long a = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+  // rebuilt as an address-space-1 pointer so that accesses stay global_* (SGPR base) instead of flat_*
+  return (T *)reinterpret_cast<AFC_AS1 T *>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ Lv uni(const Lv &L) {
   Lv U;
@@ -41,7 +42,13 @@ __device__ __forceinline__ Lv uni(const Lv &L) {
   U.r = uni(L.r);
   U.x = uni(L.x);
   U.d = uni(L.d);
-  U.desc = uni(L.desc);
+  {  // the descriptor may sit in a by-value copy of the parameters (kernel arguments / private memory in
+     // the operator kernels): keep that pointer generic
+    const unsigned long long a = reinterpret_cast<unsigned long long>(L.desc);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    U.desc = reinterpret_cast<const LevelDesc *>(((unsigned long long)hi << 32) | lo);
+  }
   return U;
 }
 struct DescU {  // the scalar fields of a LevelDesc, in SGPRs
