@@ -164,8 +164,13 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
             byv[e] = TY(i, jj);
           }
         } else if (full) {
-          __builtin_memcpy(bxv, bx + i * m + j0, sizeof(float) * C);
-          __builtin_memcpy(byv, by + i * m + j0, sizeof(float) * C);
+          // the lane offset is made opaque per row: otherwise `base + lane offset` is hoisted out of the
+          // row loop as two 64-bit lane addresses that do not fit the register file and come back from
+          // scratch, one dependent round trip each, in front of every base-field load
+          int off = i * m + j0;
+          asm volatile("" : "+v"(off));
+          __builtin_memcpy(bxv, bx + off, sizeof(float) * C);
+          __builtin_memcpy(byv, by + off, sizeof(float) * C);
         } else {
 #pragma unroll
           for (int e = 0; e < C; ++e) {
