@@ -13,7 +13,8 @@ using namespace afc;
   else                                                              \
     gs_march<true, false>(L, rr, dr, carry, zrow, dummy, I0)
 #endif
-__global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstrips, float *out, long long *ticks) {
+__global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstrips, float *out, long long *ticks,
+                                             const float *coef, int generic) {
   extern __shared__ float lds[];
   const int PW = m + kPad;
   float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
@@ -31,7 +32,9 @@ __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstri
   Lv L;
   L.n = n;
   L.m = m;
-  L.lx = L.ly = L.inv = nullptr;
+  L.lx = coef;
+  L.ly = coef + n * m + 256;
+  L.inv = coef + 2 * (n * m + 256);
   L.r = L.x = L.d = nullptr;
   L.desc = &D;
   long long t0 = 0;
@@ -39,7 +42,10 @@ __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstri
     t0 = wall_clock64();
     for (int s = 0; s < nstrips; ++s) {
       const int I0 = 17 + 16 * (s % 13);  // interior strips
-      MARCH_CALL;
+      if (generic)
+        gs_march<false>(L, rr, dr, carry, zrow, dummy, I0);
+      else
+        MARCH_CALL;
     }
     t0 = wall_clock64() - t0;
   }
@@ -68,9 +74,17 @@ int main(int argc, char **argv) {
   hipMalloc(&out, 1024 * 4);
   hipMalloc(&ticks, 1024 * 8);
   const int steps_per_strip = (m - 2 + 18 + 3) & ~3;
+  const int generic = argc > 2 ? atoi(argv[2]) : 0;
+  float *coef;
+  {
+    std::vector<float> hc(3 * (n * m + 256), 0.25f);
+    for (int q = 2 * (n * m + 256); q < 3 * (n * m + 256); ++q) hc[q] = -1.f;
+    hipMalloc(&coef, hc.size() * 4);
+    hipMemcpy(coef, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+  }
   for (int wg : {1, 256, 1024}) {
     for (int rep = 0; rep < 2; ++rep) {
-      k<<<wg, 256, lds_bytes>>>(D, n, m, nstrips, out, ticks);
+      k<<<wg, 256, lds_bytes>>>(D, n, m, nstrips, out, ticks, coef, generic);
       hipDeviceSynchronize();
     }
     std::vector<long long> h(wg);
@@ -81,7 +95,7 @@ int main(int argc, char **argv) {
     for (auto v : h) avg += (double)v;
     avg /= wg;
     const double ns = avg * 10.0 / ((double)nstrips * steps_per_strip);
-    printf("zero_bnd=%d workgroups=%4d: %.1f ns per step (%.0f cycles at 2.4 GHz), checksum %.6f\n", D.zero_bnd, wg, ns,
+    printf("generic=%d zero_bnd=%d workgroups=%4d: %.1f ns per step (%.0f cycles at 2.4 GHz), checksum %.6f\n", generic, D.zero_bnd, wg, ns,
            ns * 2.4, ho[0]);
   }
   return 0;
