@@ -92,7 +92,9 @@ typedef struct afc_config {
                            are accumulated by one thread in the reference's sequential order, making the
                            whole step bit-identical to the reference arithmetic; 0 (default): tree sums */
   int32_t impl;         /* 2 (default): optimised kernels; 0: the straightforward reference kernels
-                           (same arithmetic; kept for A/B timing and bisecting) */
+                           (same arithmetic; kept for A/B timing and bisecting).  impl 2 supports grids up to
+                           256 cells in y (y_lengths*resolution <= 256: four columns per lane); afc_create
+                           rejects taller grids with AFC_EINVAL -- create those with impl = 0 */
   int32_t stagger_us;   /* start offset between the (up to 4) envs sharing a CU, microseconds (0 = none) */
   int32_t reserved[4];
 } afc_config;
@@ -122,8 +124,13 @@ int afc_synchronize(afc_env *env);
 int afc_load_state_bdim(afc_env *env, const char *path);
 /* same, from arrays in reference layout [n*m] (u, v, p) */
 int afc_set_reset_state(afc_env *env, const float *u, const float *v, const float *p);
-/* BDIM.write (BDIM.pde:226-237) for one env */
+/* BDIM.write (BDIM.pde:226-237) for one env: `t`, `dt`, then one line `u, v, p` per cell, every number in
+ * Java's Float.toString text (what `""+u.x.a[i][j]` prints), so the file is byte-compatible with the
+ * reference's own checkpoints (clientLilypad/saved/init/init.bdim) */
 int afc_save_state_bdim(afc_env *env, int env_idx, const char *path);
+/* Java `String.valueOf(float)` / `""+f` (BDIM.pde:233, clientCFD.pde:120): shortest decimal that identifies the
+ * float32, plain notation for 1e-3 <= |x| < 1e7, otherwise d.dddE-n.  buf must hold >= 16 chars.  Host only. */
+int afc_format_float_java(float x, char *buf, int cap);
 
 /* setUpNewSim (clientCFD.pde:93-114): envs with mask[e]!=0 (all if mask==NULL) restart from
  * the reset state with t=0, xi=0.  The averaging window (callLearn, Cd, Cl) is cleared too
@@ -149,6 +156,18 @@ int afc_get_time(afc_env *env, float *t);
 int afc_get_solver_stats(afc_env *env, int32_t *iters, float *resid);
 /* diverged flag per env [E] (NaN/Inf guard; absent in the reference) */
 int afc_get_diverged(afc_env *env, uint8_t *flags);
+/* BDIM.checkCFL before the min with 1 (BDIM.pde:217 -> VectorField.CFL, VectorField.pde:225-235):
+ * out [E] = 1/(max_interior(|u|+|v|) + 3 nu).  The update2 path runs at fixed dt and never calls it
+ * (AFCCylinder.pde:46 is commented out); kept as the diagnostic the reference has. */
+int afc_get_cfl(afc_env *env, float *out);
+/* flags [E]: 1 if the env's last afc_agent_step ended because an averaging window completed (its obs is a
+ * fresh "Cl_Cd" the reference would send, clientCFD.pde:44-49), 0 if it ended only because t reached
+ * end_time or the step cap.  A window can complete on the very step that ends the episode; the reference
+ * still sends that request (draw() asks inside the step, the episode ends on the next frame). */
+int afc_get_window_complete(afc_env *env, uint8_t *flags);
+/* hist8[k] = number of pressure solves, summed over envs since the last clear, that took k+1 multigrid
+ * iterations (hist8[7]: 8 or more); the reference prints the count per solve (MG.pde:36). */
+int afc_get_mg_histogram(afc_env *env, int64_t *hist8, int clear);
 
 /* field access for one env, reference layout [n*m]; host pointers always */
 int afc_get_field(afc_env *env, int env_idx, int which, float *out);

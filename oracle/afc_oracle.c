@@ -1128,6 +1128,19 @@ void orc_refresh_coeffs(Oracle *o, float dphi1, float dphi2) {
 }
 void orc_weights(const Oracle *o, float x, float y, float *w3) { union_weights(o->bodies, x, y, w3); }
 
+float orc_cfl(const Oracle *o) { /* VectorField.CFL, VectorField.pde:225-235 (BDIM.checkCFL without the min) */
+  const VField *u = o->u;
+  int n = o->n, m = o->m;
+  float b = p_abs(A(u->x, 0, 0)) + p_abs(A(u->y, 0, 0));
+  float c;
+  for (int i = 1; i < n - 1; i++) {
+    for (int j = 1; j < m - 1; j++) {
+      c = p_abs(A(u->x, i, j)) + p_abs(A(u->y, i, j));
+      if (c > b) b = c;
+    }
+  }
+  return 1.f / (b + 3.f * o->nu);
+}
 void orc_vorticity(const Oracle *o, float *out) {
   Field *w = vf_curl(o->u);
   memcpy(out, w->a, sizeof(float) * (size_t)o->n * o->m);

@@ -63,6 +63,8 @@ void orc_refresh_coeffs(Oracle *o, float dphi1, float dphi2);
 /* per-body weights at a point (BodyUnion.get_weights, BodyUnion.pde:145-156) */
 void orc_weights(const Oracle *o, float x, float y, float *w3);
 
+/* VectorField.CFL(nu), VectorField.pde:225-235 (= BDIM.checkCFL before the min with 1, BDIM.pde:217) */
+float orc_cfl(const Oracle *o);
 /* VectorField.curl, VectorField.pde:78-87 */
 void orc_vorticity(const Oracle *o, float *out);
 /* SaveScalar.addData03 probes, SaveScalar.pde:61-72 */

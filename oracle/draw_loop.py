@@ -27,6 +27,7 @@ class OracleDrawLoop:
         self.Cd = f32(0)
         self.Cl = f32(0)
         self.obs = np.zeros(2, np.float32)
+        self.win = False
         self.reset()
 
     def reset(self, mask=None):  # setUpNewSim, clientCFD.pde:93-114
@@ -44,6 +45,7 @@ class OracleDrawLoop:
         a = np.asarray(action, np.float32).reshape(-1, 2)[0]
         xi1_m, xi2_m = self.act_scale * a[0], self.act_scale * a[1]  # clientCFD.pde:53-54
         steps = 0
+        self.win = False
         while True:
             if not (self.t < self.Time):  # clientCFD.pde:36
                 break
@@ -62,9 +64,14 @@ class OracleDrawLoop:
                     if not self.carry_quirk:
                         self.Cd = f32(0)
                         self.Cl = f32(0)
+                    self.win = True
                     break
         aa = np.abs(a)
         rew = f32(-self.obs[1] - self.penalty * f32(aa[0] * aa[0] * aa[0] + aa[1] * aa[1] * aa[1]))
         done = not (self.t < self.Time)
         return (self.obs[None, :].copy(), np.array([rew], np.float32), np.array([done], np.uint8),
                 np.array([steps], np.int32))
+
+    def window_complete(self):
+        """1 if the last agent_step ended with a completed averaging window (callAction was reached)"""
+        return np.array([1 if self.win else 0], np.uint8)

@@ -48,6 +48,8 @@ def lib():
     L.orc_get_coeff.argtypes = [C.c_void_p, C.c_int, f32p]
     L.orc_refresh_coeffs.argtypes = [C.c_void_p, C.c_float, C.c_float]
     L.orc_weights.argtypes = [C.c_void_p, C.c_float, C.c_float, f32p]
+    L.orc_cfl.argtypes = [C.c_void_p]
+    L.orc_cfl.restype = C.c_float
     L.orc_vorticity.argtypes = [C.c_void_p, f32p]
     L.orc_probes.argtypes = [C.c_void_p, C.c_int, f32p]
     L.orc_force.argtypes = [C.c_void_p, f32p]
@@ -147,6 +149,9 @@ class Oracle:
         w = np.zeros(3, np.float32)
         self._L.orc_weights(self._h, x, y, w)
         return w
+
+    def cfl(self):
+        return float(self._L.orc_cfl(self._h))
 
     def vorticity(self):
         out = np.empty((self.n, self.m), np.float32)

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/afc_env.h"
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
     s.resid[0] = sh.r0;
     s.resid[1] = sh.r1;
     s.sim_steps += 1;
+    s.it_hist[(sh.it0 < 8 ? sh.it0 : 8) - 1] += 1;
+    s.it_hist[(sh.it1 < 8 ? sh.it1 : 8) - 1] += 1;
     if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
     if (force) {
       force[2 * e] = sh.fx;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     s.xi2 = a2;
     s.xi1_m = P.act_scale * s.xi1;
     s.xi2_m = P.act_scale * s.xi2;
+    s.window_done = 0;
     s_stop = 0;
   }
   __syncthreads();
@@ -130,6 +134,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
       s.resid[0] = sh.r0;
       s.resid[1] = sh.r1;
       s.sim_steps += 1;
+      s.it_hist[(sh.it0 < 8 ? sh.it0 : 8) - 1] += 1;
+      s.it_hist[(sh.it1 < 8 ? sh.it1 : 8) - 1] += 1;
       if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
       if (s.t > P.init_time) {  // clientCFD.pde:39-47
         s.callLearn--;
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
             s.Cd = 0.f;
             s.Cl = 0.f;
           }
+          s.window_done = 1;
           s_stop = 1;
         }
       }
@@ -184,7 +191,10 @@ __global__ void k_reset(StepParams P, const uint8_t *__restrict__ mask, const fl
     EnvScalars s = G(P.sc)[e];
     const int cl = s.callLearn;
     const float cd = s.Cd, cll = s.Cl;
+    int hist[8];
+    for (int q = 0; q < 8; ++q) hist[q] = s.it_hist[q];  // diagnostics survive an episode roll-over
     s = EnvScalars{};
+    for (int q = 0; q < 8; ++q) s.it_hist[q] = hist[q];
     s.callLearn = P.substeps;
     if (keep_window) {  // clientCFD.pde:12-13 are sketch globals that setUpNewSim does not reset
       s.callLearn = cl;
@@ -223,6 +233,30 @@ __global__ void k_probes(StepParams P, const afc::SampleDev *__restrict__ ps, in
             (1 - sd.s) * (sd.t * (a[1] + sh) + (1 - sd.t) * (a[0] + sh));
     out[(size_t)e * num + q] = val;
   }
+}
+
+// VectorField.CFL (VectorField.pde:225-235) / BDIM.checkCFL (BDIM.pde:217): 1/(max(|u|+|v|) + 3 nu), the max taken
+// over the interior starting from cell [0][0]; max is order-independent, so a tree reduction gives the same bits.
+__global__ void k_cfl(StepParams P, float *__restrict__ out) {
+  __shared__ float sm[256];
+  const int e = blockIdx.x;
+  const float *x = G(P.ux) + (size_t)e * P.Ns, *y = G(P.uy) + (size_t)e * P.Ns;
+  const int n = P.n, m = P.m;
+  float b = afc::jabs(x[0]) + afc::jabs(y[0]);
+  for (int k = threadIdx.x; k < P.N; k += blockDim.x) {
+    const int i = k / m, j = k - i * m;
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float c = afc::jabs(x[k]) + afc::jabs(y[k]);
+      if (c > b) b = c;
+    }
+  }
+  sm[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && sm[threadIdx.x + s] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[e] = 1.f / (sm[0] + 3.f * P.nu);
 }
 
 // unit-level operators on env 0 (same device functions as the step)
@@ -307,8 +341,12 @@ struct afc_env {
   bool p_dirty = true;
   int cpl = 0;  // kernel instantiation: columns per lane (0 = reference kernels)
   std::vector<int> level_off;
-  afc::SampleDev *d_probes = nullptr;
+  afc::SampleDev *d_probes = nullptr;  // probe tables are cached per `num` (freed with the env)
   int n_probes = 0;
+  std::vector<std::pair<int, afc::SampleDev *>> probe_tables;
+  float *d_probe_out = nullptr;
+  size_t probe_out_cap = 0;
+  float *d_cfl = nullptr;
 };
 
 namespace {
@@ -670,6 +708,76 @@ int afc_load_state_bdim(afc_env *env, const char *path) {  // BDIM.resume, BDIM.
   return afc_set_reset_state(env, u.data(), v.data(), p.data());
 }
 
+// Java's Float.toString / String.valueOf(float) (what `""+u.x.a[i][j]` in BDIM.write and clientCFD.pde:120 produce):
+// the shortest decimal that uniquely identifies the float32, at least one digit after the point, plain notation
+// for 1e-3 <= |x| < 1e7 and d.dddE[-]n otherwise.
+int afc_format_float_java(float x, char *buf, int cap) {
+  if (!buf || cap < 16) return fail(AFC_EINVAL, "afc_format_float_java: buffer too small (need >= 16)");
+  if (std::isnan(x)) return snprintf(buf, cap, "NaN"), AFC_OK;
+  if (std::isinf(x)) return snprintf(buf, cap, x > 0 ? "Infinity" : "-Infinity"), AFC_OK;
+  if (x == 0.f) return snprintf(buf, cap, std::signbit(x) ? "-0.0" : "0.0"), AFC_OK;
+  // shortest digit string that parses back to x; among the candidates of that length the one nearest to x
+  char best[32] = "";
+  for (int p = 1; p <= 9 && !best[0]; ++p) {
+    char t[32];
+    snprintf(t, sizeof t, "%.*e", p - 1, (double)x);
+    // candidates: the correctly rounded p-digit decimal and its two neighbours in the last place
+    char mant[16];
+    int nd = 0;
+    for (const char *q = t; *q && *q != 'e'; ++q)
+      if (*q >= '0' && *q <= '9') mant[nd++] = *q;
+    mant[nd] = 0;
+    const int ex = atoi(strchr(t, 'e') + 1);
+    const long long base = atoll(mant);
+    double bestd = 1e300;
+    for (int dlt = -1; dlt <= 1; ++dlt) {
+      long long v = base + dlt;
+      int e2 = ex;
+      long long lim = 1;
+      for (int q = 0; q < p; ++q) lim *= 10;
+      if (v >= lim) {  // 9.99 + 0.01 -> 1.00e+1: one digit too many, drop the trailing zero
+        v /= 10;
+        ++e2;
+      }
+      if (v < lim / 10 && p > 1) continue;  // lost a leading digit: not a p-digit candidate
+      if (v <= 0) continue;
+      char c[40];
+      snprintf(c, sizeof c, "%s%llde%d", x < 0 ? "-" : "", v, e2 - (p - 1));
+      if (strtof(c, nullptr) != x) continue;
+      const double dd = fabs(strtod(c, nullptr) - (double)x);
+      // a tie between two candidates goes to the even last digit (FloatingDecimal.dtoa's "it's a tie" branch)
+      if (dd < bestd || (dd == bestd && (v & 1) == 0)) {
+        bestd = dd;
+        snprintf(best, sizeof best, "%lld %d", v, e2);
+      }
+    }
+  }
+  long long dig = 0;
+  int ex = 0;
+  sscanf(best, "%lld %d", &dig, &ex);
+  char ds[24];
+  snprintf(ds, sizeof ds, "%lld", dig);
+  int nd = (int)strlen(ds);
+  while (nd > 1 && ds[nd - 1] == '0') ds[--nd] = 0;  // trailing zeros carry no information
+  std::string out = (x < 0) ? "-" : "";
+  const double ax = fabs((double)x);
+  if (ax >= 1e-3 && ax < 1e7) {
+    if (ex >= 0) {
+      std::string ip(ds, ds + (nd < ex + 1 ? nd : ex + 1));
+      ip.append((size_t)(ex + 1 - (int)ip.size()), '0');
+      std::string fp = (nd > ex + 1) ? std::string(ds + ex + 1) : std::string("0");
+      out += ip + "." + fp;
+    } else {
+      out += "0." + std::string((size_t)(-ex - 1), '0') + ds;
+    }
+  } else {
+    out += std::string(1, ds[0]) + "." + (nd > 1 ? std::string(ds + 1) : std::string("0")) + "E" + std::to_string(ex);
+  }
+  if ((int)out.size() + 1 > cap) return fail(AFC_EINVAL, "afc_format_float_java: buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return AFC_OK;
+}
+
 int afc_save_state_bdim(afc_env *env, int env_idx, const char *path) {  // BDIM.write, BDIM.pde:226-237
   if (check_env(env)) return AFC_EINVAL;
   if (!path || env_idx < 0 || env_idx >= env->E) return fail(AFC_EINVAL, "afc_save_state_bdim: bad argument");
@@ -683,10 +791,20 @@ int afc_save_state_bdim(afc_env *env, int env_idx, const char *path) {  // BDIM.
   HIP_TRY(hipMemcpy(&s, G(env->P.sc) + env_idx, sizeof(s), hipMemcpyDeviceToHost));
   FILE *f = fopen(path, "w");
   if (!f) return fail(AFC_EIO, std::string("afc_save_state_bdim: cannot open ") + path);
-  // BDIM.t advances by dt per step (BDIM.pde:106); %.9g round-trips every float32
-  const float flow_t = env->reset_flow_t + (float)s.sim_steps * env->P.dt;
-  fprintf(f, "%.9g\n%.9g\n", flow_t, env->P.dt);
-  for (int k = 0; k < N; ++k) fprintf(f, "%.9g, %.9g, %.9g\n", u[k], v[k], p[k]);
+  // BDIM.t advances by dt per step (BDIM.pde:106), accumulated in float like the reference's `t += dt`
+  float flow_t = env->reset_flow_t;
+  for (int q = 0; q < s.sim_steps; ++q) flow_t += env->P.dt;
+  // output.println(t); println(dt); println(""+u+", "+v+", "+p): Java float text (BDIM.pde:229-233)
+  char a[32], b[32], c[32];
+  afc_format_float_java(flow_t, a, sizeof a);
+  afc_format_float_java(env->P.dt, b, sizeof b);
+  fprintf(f, "%s\n%s\n", a, b);
+  for (int k = 0; k < N; ++k) {
+    afc_format_float_java(u[k], a, sizeof a);
+    afc_format_float_java(v[k], b, sizeof b);
+    afc_format_float_java(p[k], c, sizeof c);
+    fprintf(f, "%s, %s, %s\n", a, b, c);
+  }
   fclose(f);
   return AFC_OK;
 }
@@ -879,26 +997,75 @@ int afc_get_probes(afc_env *env, int num, float *out) {
   if (num < 1 || num > 4096 || !out) return fail(AFC_EINVAL, "afc_get_probes: bad argument");
   HIP_TRY(hipSetDevice(env->cfg.device));
   if (env->n_probes != num) {
-    std::vector<afc::SampleDev> ps;
-    for (const auto &s : afc::build_probes(env->cp, num)) ps.push_back(to_dev(s, env->P.m));
     afc::SampleDev *d = nullptr;
-    int rc = dev_alloc(env, &d, ps.size());
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(d, ps.data(), ps.size() * sizeof(afc::SampleDev), hipMemcpyHostToDevice));
+    for (const auto &t : env->probe_tables)
+      if (t.first == num) d = t.second;
+    if (!d) {
+      std::vector<afc::SampleDev> ps;
+      for (const auto &s : afc::build_probes(env->cp, num)) ps.push_back(to_dev(s, env->P.m));
+      int rc = dev_alloc(env, &d, ps.size());
+      if (rc) return rc;
+      HIP_TRY(hipMemcpy(d, ps.data(), ps.size() * sizeof(afc::SampleDev), hipMemcpyHostToDevice));
+      env->probe_tables.emplace_back(num, d);
+    }
     env->d_probes = d;
     env->n_probes = num;
   }
-  float *dout = nullptr;
-  HIP_TRY(hipMalloc(&dout, (size_t)env->E * num * sizeof(float)));
-  hipLaunchKernelGGL(k_probes, dim3(env->E), dim3(64), 0, env->stream, env->P, env->d_probes, num, dout);
-  int rc = launch_check("k_probes");
-  if (!rc) {
-    hipError_t e = hipStreamSynchronize(env->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)env->E * num * sizeof(float), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(AFC_EHIP, hipGetErrorString(e));
+  const size_t need = (size_t)env->E * num;
+  if (need > env->probe_out_cap) {  // persistent output staging, grown when a larger `num` is asked for
+    float *q = nullptr;
+    int rc = dev_alloc(env, &q, need);
+    if (rc) return rc;
+    env->d_probe_out = q;
+    env->probe_out_cap = need;
   }
-  (void)hipFree(dout);
-  return rc;
+  hipLaunchKernelGGL(k_probes, dim3(env->E), dim3(64), 0, env->stream, env->P, env->d_probes, num, env->d_probe_out);
+  int rc = launch_check("k_probes");
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, env->d_probe_out, need * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  return AFC_OK;
+}
+
+int afc_get_cfl(afc_env *env, float *out) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!out) return fail(AFC_EINVAL, "afc_get_cfl: null out");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  if (!env->d_cfl) {
+    int rc = dev_alloc(env, &env->d_cfl, (size_t)env->E);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_cfl, dim3(env->E), dim3(256), 0, env->stream, env->P, env->d_cfl);
+  int rc = launch_check("k_cfl");
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, env->d_cfl, (size_t)env->E * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  return AFC_OK;
+}
+
+int afc_get_window_complete(afc_env *env, uint8_t *flags) {
+  if (check_env(env) || !flags) return fail(AFC_EINVAL, "afc_get_window_complete: bad argument");
+  std::vector<EnvScalars> h;
+  int rc = fetch_scalars(env, h);
+  if (rc) return rc;
+  for (int e = 0; e < env->E; ++e) flags[e] = h[e].window_done ? 1 : 0;
+  return AFC_OK;
+}
+
+int afc_get_mg_histogram(afc_env *env, int64_t *hist8, int clear) {
+  if (check_env(env) || !hist8) return fail(AFC_EINVAL, "afc_get_mg_histogram: bad argument");
+  std::vector<EnvScalars> h;
+  int rc = fetch_scalars(env, h);
+  if (rc) return rc;
+  for (int q = 0; q < 8; ++q) hist8[q] = 0;
+  for (int e = 0; e < env->E; ++e)
+    for (int q = 0; q < 8; ++q) hist8[q] += h[e].it_hist[q];
+  if (clear) {
+    for (auto &s : h)
+      for (int q = 0; q < 8; ++q) s.it_hist[q] = 0;
+    HIP_TRY(hipMemcpy(G(env->P.sc), h.data(), env->E * sizeof(EnvScalars), hipMemcpyHostToDevice));
+  }
+  return AFC_OK;
 }
 
 int afc_get_static(afc_env *env, int which, int level, float *out) {

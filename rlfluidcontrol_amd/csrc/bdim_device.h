@@ -65,8 +65,9 @@ struct EnvScalars {  // per-env episode state (clientCFD.pde globals + AFCCylind
   float resid[2];
   int diverged;
   int sim_steps;     // total since reset
-  float p_shift;     // reserved (deferred mean shift)
-  int pad;
+  float p_shift;     // deferred mean shift of the last projection (bdim_v2.h)
+  int window_done;   // 1: the last agent step ended because an averaging window completed (obs is fresh)
+  int it_hist[8];    // pressure solves since the last clear that took 1,2,...,7,>=8 MG iterations
 };
 
 struct StepParams {

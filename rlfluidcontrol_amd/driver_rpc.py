@@ -10,6 +10,12 @@ server/server.py (or any server exposing the same 8 methods, server.py:51-59).
 The simulation itself is the batched HIP environment (`AFCEnv.agent_step` runs the body of
 draw() between two action requests on the GPU); this module only does the protocol.  The server
 is stateful for exactly one episode, so the driver uses env index 0 of the batch.
+
+Drop-in note: the sketch never clears its `Cd`/`Cl` globals after a request (clientCFD.pde:41-47), so every
+window after the first starts from the previous normalised mean (~0.5 % carry) and the sums leak across
+episodes.  An unchanged server.py sees exactly the reference client's strings only when the env is built with
+`carry_quirk=1`: use `LilypadRPCDriver.reference_env(...)`.  `carry_quirk=0` (the library default, used by
+train.py and bench.py) is the cleaned-up averaging and is a stated deviation from the reference client.
 """
 import xmlrpc.client
 
@@ -19,8 +25,19 @@ from .javafmt import java_float_to_string, java_parse_float
 
 
 class LilypadRPCDriver:
+    @staticmethod
+    def reference_env(resolution=24, reynolds=500, **kw):
+        """One HIP env configured like the reference sketch, including its Cd/Cl carry (clientCFD.pde:41-47)."""
+        from .env import AFCEnv
+        kw.setdefault("carry_quirk", 1)
+        return AFCEnv(num_envs=1, resolution=resolution, reynolds=reynolds, **kw)
+
     def __init__(self, env, url="http://localhost:8000", train_steps=1000, deterministic=False, log=None):
         self.env = env
+        cfg = getattr(env, "cfg", None)
+        if cfg is not None and not getattr(cfg, "carry_quirk", 1) and log is not None:
+            log("note: env built with carry_quirk=0 -- observations deviate from the reference client's by its "
+                "Cd/Cl carry (use LilypadRPCDriver.reference_env for drop-in strings)")
         self.client = xmlrpc.client.ServerProxy(url, allow_none=True)
         self.train_steps = train_steps
         self.method = "request_deterministic_action" if deterministic else "request_stochastic_action"
@@ -64,13 +81,16 @@ class LilypadRPCDriver:
         n = 0
         while True:
             obs, _rew, done, ns = self.env.agent_step(action)
-            if done[0] and ns[0] < 1:
+            # a window that completes on the very step that takes t to Time is still sent (draw() asks inside
+            # the step and only ends the episode on the next frame, clientCFD.pde:36-56,67); a window cut short
+            # by t >= Time is not
+            fresh = (not done[0]) or bool(self.env.window_complete()[0])
+            if fresh:
+                xi = self.call_action(obs[0, 0], obs[0, 1])
+                action[:] = xi[None, :]
+                n += 1
+            if done[0]:
                 break
-            if done[0]:  # the window that was running when t reached Time never completes
-                break
-            xi = self.call_action(obs[0, 0], obs[0, 1])
-            action[:] = xi[None, :]
-            n += 1
             if max_requests is not None and n >= max_requests:
                 break
         return n

@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "afc_load_state_bdim", "afc_set_reset_state", "afc_save_state_bdim", "afc_reset", "afc_sim_step",
     "afc_agent_step", "afc_get_time", "afc_get_solver_stats", "afc_get_diverged", "afc_get_field",
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
-    "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases",
+    "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases", "afc_format_float_java", "afc_get_cfl",
+    "afc_get_window_complete", "afc_get_mg_histogram",
 ]
 
 
@@ -92,6 +93,10 @@ def load_library():
     L.afc_op_mg_solve.argtypes = [vp, f32p, f32p, i32p, C.POINTER(C.c_float)]
     L.afc_op_setbc_u.argtypes = [vp, f32p, f32p]
     L.afc_profile_phases.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.afc_format_float_java.argtypes = [C.c_float, C.c_char_p, C.c_int]
+    L.afc_get_cfl.argtypes = [vp, f32p]
+    L.afc_get_window_complete.argtypes = [vp, u8p]
+    L.afc_get_mg_histogram.argtypes = [vp, vp, C.c_int]
     _lib = L
     return L
 
@@ -108,6 +113,15 @@ def default_config(**overrides):
             raise AfcError("unknown config key %r" % k)
         setattr(cfg, k, v)
     return cfg
+
+
+def java_float_text(x):
+    """Float.toString(x) as the C library prints it in .bdim files (afc_format_float_java)."""
+    L = load_library()
+    buf = C.create_string_buffer(32)
+    if L.afc_format_float_java(C.c_float(float(x)), buf, 32) != 0:
+        raise AfcError(L.afc_last_error().decode())
+    return buf.value.decode()
 
 
 def _np_ptr(a):
@@ -238,6 +252,23 @@ class AFCEnv:
         rs = np.empty((self.num_envs, 2), np.float32)
         self._ck(self._L.afc_get_solver_stats(self._h, _np_ptr(it), _np_ptr(rs)), "afc_get_solver_stats")
         return it, rs
+
+    def cfl(self):
+        """BDIM.checkCFL without the min(.,1) (VectorField.pde:225-235) per env."""
+        out = np.empty(self.num_envs, np.float32)
+        self._ck(self._L.afc_get_cfl(self._h, _np_ptr(out)), "afc_get_cfl")
+        return out
+
+    def window_complete(self):
+        out = np.empty(self.num_envs, np.uint8)
+        self._ck(self._L.afc_get_window_complete(self._h, _np_ptr(out)), "afc_get_window_complete")
+        return out
+
+    def mg_histogram(self, clear=False):
+        """solves that took 1..7, >=8 multigrid iterations since the last clear (all envs)"""
+        out = np.zeros(8, np.int64)
+        self._ck(self._L.afc_get_mg_histogram(self._h, _np_ptr(out), int(clear)), "afc_get_mg_histogram")
+        return out
 
     def diverged(self):
         out = np.empty(self.num_envs, np.uint8)

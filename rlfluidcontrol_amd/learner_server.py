@@ -106,8 +106,9 @@ class LearnerServer:
         return True
 
     def _restore(self, episode_count):  # server.py:192-198
+        # plain tensors / numbers only: nothing in the save dir is unpickled as code
         sd = torch.load(os.path.join(self.save_model_dir, "{}.pt".format(episode_count)), map_location=self.agent.device,
-                        weights_only=False)
+                        weights_only=True)
         self.agent.load_state_dict(sd)
         self.agent.episode_count = episode_count
         return True

@@ -138,11 +138,14 @@ class ReplayBuffer:
                     max_size=self.max_size)
 
     def load_state_dict(self, sd):
-        n = sd["size"]
+        n = int(sd["size"])
+        if int(sd.get("max_size", self.max_size)) != self.max_size or n > self.max_size or not (0 <= int(sd["ptr"]) < self.max_size):
+            raise ValueError("replay buffer checkpoint (max_size %s, size %s, ptr %s) does not fit a buffer of %d"
+                             % (sd.get("max_size"), sd["size"], sd["ptr"], self.max_size))
         for name, key in (("obs1_buf", "obs1"), ("obs2_buf", "obs2"), ("acts_buf", "acts"), ("rews_buf", "rews"),
                           ("done_buf", "done")):
             getattr(self, name)[:n] = sd[key].to(self.device)
-        self.ptr, self.size = sd["ptr"], sd["size"]
+        self.ptr, self.size = int(sd["ptr"]), n
 
 
 def _mlp(sizes, last):
@@ -281,7 +284,9 @@ class Agent:
         self.P_opt.load_state_dict(sd["P_opt"])
         self.replay_buffer.load_state_dict(sd["replay"])
         self.episode_count = sd["episode_count"]
-        self.total_step_count = sd["total_step_count"]
+        # total_step_count is NOT restored: in the reference it is a plain Python attribute outside the TF
+        # checkpoint and the pickled buffer (server.py:192-198, agent_TD3.py:167-173), so a restored agent
+        # restarts its policy-delay phase from 0; the saved value is kept in the file for information only
 
 
 def assemble_transitions(state_record, action_record, action_dim):

@@ -8,13 +8,19 @@ replay buffer never leave HBM; at the end of an episode the E x 407 transitions 
 
     python -m rlfluidcontrol_amd.train --envs 1024 --episodes 2 --train-steps 1000
 
-Multi-GPU: launch one process per GPU (torchrun); every rank steps its shard, the one all-gather
-per agent step of `ShardedVecEnv` gives every rank the global observation, and the learner is
-REPLICATED (same seed, same inputs => same weights and actions on every rank), so no gradient
-collective is needed for a 0.2 M-parameter model.
+Multi-GPU (cfg5: 8 x MI355X): one process per GPU over RCCL,
+    python -m rlfluidcontrol_amd.train --gpus 8 --envs 1024        (spawns the ranks itself), or
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m rlfluidcontrol_amd.train ...
+Every rank steps its shard, the one all-gather per agent step of `ShardedVecEnv` gives every rank the global
+observation, and the learner is REPLICATED (same seed, same inputs => same weights and actions on every
+rank), so no gradient collective is needed for a 0.2 M-parameter model.  The reference's only RL collective is
+the same shape: rank 0 talks to the agent and `MPI_Bcast`s the two action values
+(clientNektar/Fourier/src/drive.C:1561); here every rank evaluates the same actor on the same gathered obs.
 """
 import argparse
 import json
+import os
+import sys
 import time
 
 import torch
@@ -31,13 +37,16 @@ def run_episode(vec, learner, max_requests=None, stochastic=True):
     n, rew_sum = 0, 0.0
     while True:
         obs, rew, done = vec.step(action)
-        if bool(done.all()):  # the window running when t reached Time never completes (clientCFD.pde:36)
+        ended = bool(done.all())
+        # all envs run the same fixed-dt episode in lock-step; a window that completes on the step that takes t
+        # to Time is still sent by the reference (clientCFD.pde:36-56), one cut short by t >= Time is not
+        if ended and not vec.window_complete():
             break
         action = learner.request_action(obs, stochastic=stochastic)
         if n > 0:
             rew_sum += float(rew.mean())
         n += 1
-        if max_requests is not None and n >= max_requests:
+        if ended or (max_requests is not None and n >= max_requests):
             break
     return n, rew_sum / max(n - 1, 1)
 
@@ -49,6 +58,10 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
     build.build()
     dev = torch.device(device)
     torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank != 0:
+        log = (lambda *_a: None)  # one log line per episode, from rank 0
     g = envmod.AFCEnv(num_envs=num_envs, resolution=resolution, reynolds=reynolds, device=dev.index or 0,
                       **(env_kwargs or {}))
     if init is not None:
@@ -68,7 +81,8 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
         torch.cuda.synchronize(dev)
         t2 = time.time()
         rec = dict(episode=ep + 1, requests=n, mean_reward=mean_r, rollout_s=t1 - t0, train_s=t2 - t1,
-                   buffer=learner.agent.replay_buffer.size, td3_iters=learner.agent.total_step_count)
+                   buffer=learner.agent.replay_buffer.size, td3_iters=learner.agent.total_step_count,
+                   world=vec.world, envs_total=vec.world * num_envs, collectives=vec.n_collectives)
         history.append(rec)
         log(json.dumps(rec))
     g.close()
@@ -86,9 +100,38 @@ def main(argv=None):
     ap.add_argument("--filter", choices=["None", "Kalman"], default="None")
     ap.add_argument("--explore-noise", choices=["Gaussian", "Process"], default="Gaussian")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to spawn (one per GPU) when not started by a launcher")
+    ap.add_argument("--init", default=None, help=".npz with u, v, p: the reset state (default: free stream)")
     a = ap.parse_args(argv)
-    train(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, episodes=a.episodes, train_steps=a.train_steps,
-          max_requests=a.max_requests, filter=a.filter, explore_noise=a.explore_noise, seed=a.seed)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # become the launcher BEFORE anything touches a GPU in this process
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "rlfluidcontrol_amd.train"]
+        raise SystemExit(subprocess.call(cmd + list(sys.argv[1:] if argv is None else argv)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    init = None
+    if a.init:
+        import numpy as np
+        init = np.load(a.init)
+    try:
+        train(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, episodes=a.episodes, train_steps=a.train_steps,
+              max_requests=a.max_requests, filter=a.filter, explore_noise=a.explore_noise, seed=a.seed, device=dev,
+              init=init)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

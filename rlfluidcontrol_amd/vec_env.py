@@ -43,6 +43,12 @@ class ShardedVecEnv:
         g = self.gathered
         return g[:, 0:2], g[:, 2], g[:, 3] > 0.5
 
+    def window_complete(self):
+        """True if the last step ended with a completed averaging window (lock-step episodes: env 0 of this
+        rank speaks for all; only consulted on the step that ends an episode)"""
+        f = getattr(self.backend, "window_complete", None)
+        return bool(f()) if f is not None else False
+
     def reset_done(self, done_global):
         self.backend.reset_mask(done_global[self.local_slice()].to(torch.uint8).contiguous())
 
@@ -68,3 +74,6 @@ class HipBackend:
 
     def reset_mask(self, mask_u8):
         self.env.reset(mask_u8.data_ptr())
+
+    def window_complete(self):
+        return bool(self.env.window_complete()[0])

@@ -1,0 +1,261 @@
+"""GPU tests added in round 2: the CFL read-out, the Java-text checkpoint writer and reference-format reader,
+the XML-RPC boundary over the HIP env (BASELINE cfg1), the window-on-last-step protocol edge, the full-size
+cfg4 / cfg5 workloads, the default-mode tolerance at res 32, and the 2-rank RCCL gather (when 2 GPUs exist)."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+from oracle.draw_loop import OracleDrawLoop
+from tests.standin_server import StandInServer
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def envmod():
+    from rlfluidcontrol_amd import build, env
+    build.build()
+    return env
+
+
+def test_cfl_matches_oracle(envmod, oracle_mod):
+    """BDIM.checkCFL / VectorField.CFL (VectorField.pde:225-235) of the live state, bit for bit"""
+    g = envmod.AFCEnv(num_envs=3, resolution=8, reynolds=100, exact_sums=1)
+    o = oracle_mod.Oracle(resolution=8, Re=100)
+    assert np.array_equal(g.cfl(), np.full(3, o.cfl(), np.float32))  # free stream: 1/(1 + 3 nu)
+    xi = np.array([[4.0, -3.0]] * 3, np.float32)
+    for _ in range(3):
+        g.update2(xi)
+        o.update2(4.0, -3.0)
+        c = g.cfl()
+        assert c[0] == np.float32(o.cfl()) and c[0] == c[1] == c[2]
+    assert 0.2 < c[0] < 0.8  # |u|+|v| of a few near the spinning cylinders
+    g.close()
+
+
+def test_bdim_writer_is_java_text_and_reference_format_reads_back(envmod, init_bdim, tmp_path):
+    """BDIM.write/resume (BDIM.pde:226-251): our writer reproduces the reference checkpoint's own lines for the
+    same values, and a file in the reference's number format (incl. E-notation) loads to the same bits."""
+    g = envmod.AFCEnv(num_envs=1, resolution=24, reynolds=500)
+    g.set_reset_state(init_bdim["u"], init_bdim["v"], init_bdim["p"])
+    path = os.path.join(tmp_path, "w.bdim")
+    g.write(path)
+    lines = open(path).read().split("\n")
+    n, m = init_bdim["u"].shape
+    assert len(lines) == 2 + n * m + 1 and lines[-1] == ""
+    assert lines[1] == str(init_bdim["head_text"][1])  # dt = 0.17999999
+    head = [str(s) for s in init_bdim["head_text"][2:]]
+    assert lines[2:2 + len(head)] == head
+    tail = [str(s) for s in init_bdim["tail_text"]]
+    assert lines[2 + n * m - len(tail):2 + n * m] == tail
+    assert all(re.fullmatch(r"(-?\d+\.\d+(E-?\d+)?)(, -?\d+\.\d+(E-?\d+)?){2}", l) for l in lines[2:2 + n * m:997])
+    # a state with tiny values prints E-notation ("8.5E-4" style); the reader must take it
+    rng = np.random.default_rng(3)
+    u = (init_bdim["u"] * 1e-4).astype(np.float32)
+    v = (rng.standard_normal((n, m)) * 1e-6).astype(np.float32)
+    p = (init_bdim["p"] * 3e7).astype(np.float32)
+    g.set_reset_state(u, v, p)
+    g.write(path)
+    txt = open(path).read()
+    assert "E-" in txt and re.search(r"\dE\d", txt)
+    h = envmod.AFCEnv(num_envs=2, resolution=24, reynolds=500)
+    h.resume(path)
+    for e in range(2):
+        u2, v2, p2 = h.get_state(e)
+        assert np.array_equal(u2, u) and np.array_equal(v2, v) and np.array_equal(p2, p)
+    g.close()
+    h.close()
+
+
+def test_mg_histogram_counts_every_solve(envmod):
+    g = envmod.AFCEnv(num_envs=4, resolution=8, reynolds=100)
+    assert g.mg_histogram().sum() == 0
+    xi = np.zeros((4, 2), np.float32)
+    for _ in range(5):
+        g.update2(xi)
+    h = g.mg_histogram()
+    assert h.sum() == 4 * 5 * 2 and h[0] > 0  # two pressure solves per env per sim-step
+    it, _ = g.solver_stats()
+    assert h[int(it.max()) - 1] > 0
+    g.agent_step(np.zeros((4, 2), np.float32))
+    h2 = g.mg_histogram(clear=True)
+    assert h2.sum() > h.sum() and g.mg_histogram().sum() == 0
+    g.close()
+
+
+def test_rpc_boundary_over_the_hip_env_cfg1(envmod):
+    """BASELINE cfg1 plumbing: our counterpart of clientCFD.pde drives ONE HIP env (128x64, Re 100) against the
+    stand-in for server.py over real XML-RPC; in parity mode the whole transcript (every "Cl_Cd" string sent and
+    every action received) is identical to the run with the CPU draw-loop oracle behind the same driver."""
+    from rlfluidcontrol_amd.driver_rpc import LilypadRPCDriver
+
+    def run(env):
+        srv = StandInServer().start()
+        try:
+            drv = LilypadRPCDriver(env, url="http://127.0.0.1:%d" % srv.port, train_steps=1000)
+            drv.run(episodes=1)
+            return drv.transcript, list(srv.calls), list(srv.rewards)
+        finally:
+            srv.stop()
+
+    kw = dict(init_time=0.05, end_time=0.62)
+    g = LilypadRPCDriver.reference_env(resolution=8, reynolds=100, exact_sums=1, **kw)
+    assert g.cfg.carry_quirk == 1
+    tg, cg, rg = run(g)
+    to, co, ro = run(OracleDrawLoop(resolution=8, Re=100, carry_quirk=True, **kw))
+    assert tg == to and cg == co and rg == ro
+    names = [c[0] for c in cg]
+    assert names[:2] == ["init", "start_episode"] and names.count("request_stochastic_action") == 4
+    assert names[names.index("train") + 1] == "save"
+    g.close()
+
+
+def test_window_completing_on_the_last_step_is_still_sent(envmod):
+    """clientCFD.pde:36-56: draw() asks for the action inside the step and only ends the episode on the next
+    frame, so a window that completes on the step that takes t to Time is sent; one cut short is not."""
+    from rlfluidcontrol_amd.driver_rpc import LilypadRPCDriver
+    t = f32(0)
+    per = f32(f32(f32(0.0075) * f32(8)) / f32(8))
+    for _ in range(32):
+        t = f32(t + per)
+    for end, want_reqs in ((float(t), 2), (float(t) + 0.004, 2), (float(t) - 0.004, 2), (float(t) - 0.01, 1)):
+        kw = dict(init_time=-1.0, end_time=end)
+        res = []
+        for env in (LilypadRPCDriver.reference_env(resolution=8, reynolds=100, exact_sums=1, **kw),
+                    OracleDrawLoop(resolution=8, Re=100, carry_quirk=True, **kw)):
+            srv = StandInServer().start()
+            try:
+                drv = LilypadRPCDriver(env, url="http://127.0.0.1:%d" % srv.port)
+                drv.setup()
+                n = drv.run_episode()
+                res.append((n, [c for c in srv.calls if c[0].startswith("request")]))
+            finally:
+                srv.stop()
+            if hasattr(env, "close"):
+                env.close()
+        assert res[0] == res[1] and res[0][0] == want_reqs, (end, res)
+
+
+def test_default_mode_tolerance_at_res32(envmod, oracle_mod):
+    """the mode bench.py times (tree sums for Field.sum / Field.inner) on the 512x256 Re 400 grid, 16 steps with
+    actuation, against the oracle: same stated tolerance as on the smaller grids (tests/test_gpu_parity.py)"""
+    res, Re = 32, 400
+    g = envmod.AFCEnv(num_envs=2, resolution=res, reynolds=Re)
+    o = oracle_mod.Oracle(resolution=res, Re=Re)
+    rng = np.random.default_rng(11)
+    mx = 0.0
+    for k in range(16):
+        a = (0.0, 0.0) if k < 2 else tuple(5 * rng.uniform(-1, 1, 2))
+        fg = g.update2(np.tile(np.array([a], np.float32), (2, 1)))
+        fo, ito, _ = o.update2(float(f32(a[0])), float(f32(a[1])))
+        assert np.array_equal(fg[0], fg[1])
+        sc = max(1.0, float(np.abs(fo).max()))
+        assert np.abs(fg[0].astype(np.float64) - fo).max() <= 5e-5 * sc * res / 2, (k, fg[0], fo)  # forces are O(res)
+        mx = max(mx, float(np.abs(fg[0].astype(np.float64) - fo).max()) / sc)
+    ug, vg, pg = g.get_state(0)
+    uo, vo, po = o.get_state()
+    assert np.abs(ug.astype(np.float64) - uo).max() <= 5e-6 and np.abs(vg.astype(np.float64) - vo).max() <= 5e-6
+    assert np.abs(pg.astype(np.float64) - po).max() <= 5e-4 * max(1.0, float(np.abs(po).max()))
+    itg, _ = g.solver_stats()
+    assert tuple(itg[0]) == tuple(ito)
+    g.close()
+
+
+def test_cfg4_full_size_1024_envs_512x256(envmod):
+    """BASELINE cfg4 at its own size: 1024 envs on the 512x256 Re 400 grid (level 1 streams, 8 MG levels).  All envs
+    get the same inputs: they must stay bit-identical to each other and to a single env run alone, with no
+    divergence, one V-cycle per solve after the start-up."""
+    E, res, Re = 1024, 32, 400
+    g = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re)
+    one = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re)
+    acts = [(0.0, 0.0), (2.5, -4.0), (2.5, -4.0), (-1.0, 3.0)]
+    for a in acts:
+        fg = g.update2(np.tile(np.array([a], np.float32), (E, 1)))
+        f1 = one.update2(np.array([a], np.float32))
+        assert np.all(fg == fg[0]) and np.array_equal(fg[0], f1[0])
+    assert g.diverged().sum() == 0
+    for e in (0, 255, 256, 777, 1023):
+        for x, y in zip(g.get_state(e), one.get_state(0)):
+            assert np.array_equal(x, y)
+    it, rs = g.solver_stats()
+    assert it.max() <= 2 and np.all(np.isfinite(rs))
+    c = g.cfl()
+    assert np.all(c == c[0]) and c[0] == one.cfl()[0]
+    g.close()
+    one.close()
+
+
+def test_cfg5_td3_in_the_loop_at_1024_envs(envmod):
+    """BASELINE cfg5's per-GPU workload: 1024 envs x 256x128 with the TD3 learner on the same device -- the
+    episode protocol up to the 8th request (149 + 7x16 sim-steps per env), transitions assembled, 8 TD3 iterations."""
+    import torch
+
+    from rlfluidcontrol_amd import td3, train
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wake_res16_re100.npz"))
+    learner, hist = train.train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=8, seed=2,
+                                max_requests=8, init=z, log=lambda s: None)
+    h = hist[0]
+    assert h["requests"] == 8 and h["buffer"] == 7 * 1024 and h["td3_iters"] == 8 and h["world"] == 1
+    ag = learner.agent
+    n = ag.replay_buffer.size
+    s1, s2, a, r = (ag.replay_buffer.obs1_buf[:n], ag.replay_buffer.obs2_buf[:n], ag.replay_buffer.acts_buf[:n],
+                    ag.replay_buffer.rews_buf[:n, 0])
+    assert torch.isfinite(s1).all() and torch.isfinite(s2).all() and torch.isfinite(r).all()
+    assert torch.allclose(r, td3.reward_func(s2, a), atol=1e-6) and float(a.abs().max()) <= 1.0
+    last = s2[n - 1024:n]
+    assert float(last[:, 1].std()) > 1e-4          # envs decorrelate under their own exploration noise
+    assert 0.5 < float(last[:, 1].mean()) < 3.0    # Cd of a Re-100 cylinder wake
+
+
+def _rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from rlfluidcontrol_amd import build, env
+        from rlfluidcontrol_amd.vec_env import HipBackend, ShardedVecEnv
+        build.build()
+        E = 4
+        g = env.AFCEnv(num_envs=E, resolution=8, reynolds=100, device=rank, init_time=0.0, end_time=10.0)
+        ve = ShardedVecEnv(HipBackend(g, dev), E, device=dev)
+        gen = torch.Generator().manual_seed(5)
+        outs = []
+        for _ in range(3):
+            act = (torch.rand(world * E, 2, generator=gen) * 2 - 1).to(dev)  # same tensor on every rank
+            obs, rew, done = ve.step(act)
+            outs.append(torch.cat([obs.reshape(-1), rew, done.float()]).cpu())
+        q.put((rank, ve.n_collectives, torch.stack(outs).numpy()))
+        g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gpu_gather_every_rank_sees_the_same_batch():
+    """one RCCL all-gather of (obs, reward, done) per agent step; needs 2 GPUs (skipped otherwise)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    assert res[0][1] == res[1][1] == 3                # n_collectives == agent steps
+    assert np.array_equal(res[0][2], res[1][2])        # identical gathered (obs, reward, done) on both ranks
+    obs = res[0][2][:, :16].reshape(3, 8, 2)
+    assert not np.array_equal(obs[2, :4], obs[2, 4:])  # the two shards ran different actions

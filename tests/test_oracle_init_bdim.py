@@ -80,3 +80,56 @@ def test_actuated_steps_anchor(init_bdim, oracle_mod):
     assert abs(f[1] * 2 / 24 - 0.0309722) < 5e-6
     ubx = o.coeff("ub.x")
     assert np.count_nonzero(ubx) > 50 and np.count_nonzero(ubx) < 400
+
+
+def test_field_level_continuity_from_init_bdim(init_bdim, oracle_mod):
+    """Field-level pin (the checkpoint is a developed, smoothly evolving wake at fixed dt): continuing it with
+    the oracle, the first step away from the REFERENCE's state (u1-u0) must look like the oracle's own next
+    step (u2-u1) -- a mis-restated operator (QUICK constant, diffusion weight, forcing, projection sign) makes
+    the first difference a start-up jump and the second difference as large as the first.  The oracle's OUTPUT
+    states must also reproduce the checkpoint's own invariants at the checkpoint's own levels.
+    Numbers measured with the committed oracle (max-norm, float64 differences of float32 fields):
+        u: |u1-u0| 1.1404e-2  |u2-u1| 1.1413e-2  |u2-2u1+u0| 4.31e-4   (ratio 0.038)
+        v: |v1-v0| 1.8674e-2  |v2-v1| 1.8645e-2  |v2-2v1+v0| 7.13e-4   (ratio 0.038)
+        p: |p1-p0| 1.0689e-2  |p2-p1| 1.0678e-2  |p2-2p1+p0| 3.04e-3   (ratio 0.28: p is only solved to the
+           reference's tolerance, one V-cycle, residual L_inf 4e-5 -> pointwise noise of a few 1e-3)
+        checkpoint:  mean p -1.9e-7, outflow mean 1+2.5e-7, sum div^2 2.190e-9, max|div| (outflow column) 4.14e-3
+        oracle out:  mean p +-1.3e-7, outflow mean 1+-3.5e-8, sum div^2 2.11e-9..2.21e-9, max|div| 3.94e-3..4.08e-3"""
+    o = oracle_mod.Oracle(resolution=24, Re=500)
+    o.set_state(init_bdim["u"], init_bdim["v"], init_bdim["p"])
+    S = [tuple(init_bdim[k].astype(np.float64) for k in ("u", "v", "p"))]
+    outs = []
+    for _ in range(3):
+        _, it, _ = o.update2(0.0, 0.0)
+        assert it == (1, 1)
+        st = o.get_state()
+        outs.append(st)
+        S.append(tuple(a.astype(np.float64) for a in st))
+    n, m = init_bdim["u"].shape
+    report = {}
+    for idx, (name, lim) in enumerate((("u", 0.1), ("v", 0.1), ("p", 0.35))):
+        a0, a1, a2, a3 = (s[idx] for s in S)
+        d1, d2 = np.abs(a1 - a0).max(), np.abs(a2 - a1).max()
+        dd01, dd12 = np.abs(a2 - 2 * a1 + a0).max(), np.abs(a3 - 2 * a2 + a1).max()
+        report[name] = (d1, d2, dd01, dd12)
+        assert dd01 <= lim * d1, (name, dd01, d1)          # no jump when leaving the reference's state
+        assert abs(d1 - d2) <= 0.02 * d1, (name, d1, d2)     # the step away from it is as large as the oracle's next one
+        assert dd01 <= 1.6 * dd12 + 1e-12, (name, dd01, dd12)  # and no rougher than the oracle following itself
+        # RMS version (insensitive to single cells)
+        r1 = np.sqrt(((a1 - a0) ** 2).mean())
+        rdd = np.sqrt(((a2 - 2 * a1 + a0) ** 2).mean())
+        assert rdd <= lim * r1, (name, rdd, r1)
+    print("field-level continuity (d1, d2, dd01, dd12):", report)
+    u0, v0 = init_bdim["u"], init_bdim["v"]
+    div0 = (u0[2:, 1:-1] - u0[1:-1, 1:-1] + v0[1:-1, 2:] - v0[1:-1, 1:-1]).astype(np.float64)
+    ref_sdiv2, ref_maxdiv = (div0[:-1] ** 2).sum(), np.abs(div0).max()
+    for u, v, p in outs:
+        assert abs(p[1:-1, 1:-1].astype(np.float64).mean()) < 5e-7                      # VectorField.pde:136
+        assert abs(u[n - 1, 1:m - 1].astype(np.float64).mean() - 1.0) < 2.5e-7          # Field.pde:230-233
+        assert np.all(u[1, :] == 1.0) and np.all(u[0, :] == u[1, :]) and np.all(v[:, 1] == 0) and np.all(v[:, 0] == 0)
+        assert np.all(p[0, 1:-1] == p[1, 1:-1]) and np.all(p[:, 0] == p[:, 1])
+        div = (u[2:, 1:-1] - u[1:-1, 1:-1] + v[1:-1, 2:] - v[1:-1, 1:-1]).astype(np.float64)
+        sdiv2, maxdiv = (div[:-1] ** 2).sum(), np.abs(div).max()
+        # the projection leaves the SAME residual divergence level the reference's own state has
+        assert 0.8 * ref_sdiv2 < sdiv2 < 1.25 * ref_sdiv2, (sdiv2, ref_sdiv2)
+        assert 0.85 * ref_maxdiv < maxdiv < 1.1 * ref_maxdiv and np.abs(div[-1]).max() == maxdiv  # outflow column

@@ -75,10 +75,33 @@ def report_insts(d):
         prev = cur
 
 
+def report_counters(d):
+    """every counter found in the pass, per phase, per env (generic form of report_insts)"""
+    names = set()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_sim_step" in r["Kernel_Name"]:
+                names.add(r["Counter_Name"])
+    names = sorted(names)
+    cols = [series(d, c) for c in names]
+    prev = [0.0] * len(names)
+    print("%-34s " % "phase" + " ".join("%22s" % n for n in names) + "   (per env)")
+    for i, st in enumerate(STOPS):
+        cur = [c[i] / E for c in cols]
+        if st == 0:
+            print("%-34s " % "whole step" + " ".join("%22.0f" % v for v in cur))
+            continue
+        half, ph = divmod(st - 1, 8)
+        print("%-34s " % ("half %d %s" % (half, NAMES[ph])) + " ".join("%22.0f" % (a - b) for a, b in zip(cur, prev)))
+        prev = cur
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
     elif sys.argv[1] == "insts":
         report_insts(sys.argv[2])
+    elif sys.argv[1] == "counters":
+        report_counters(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3])
