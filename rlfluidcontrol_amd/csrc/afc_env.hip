@@ -75,8 +75,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
     s.resid[0] = sh.r0;
     s.resid[1] = sh.r1;
     s.sim_steps += 1;
-    s.it_hist[(sh.it0 < 8 ? sh.it0 : 8) - 1] += 1;
-    s.it_hist[(sh.it1 < 8 ? sh.it1 : 8) - 1] += 1;
+    s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;  // clamped: diagnostic launches that leave the step early
+    s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;  // do not fill sh
     if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
     if (force) {
       force[2 * e] = sh.fx;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
       s.resid[0] = sh.r0;
       s.resid[1] = sh.r1;
       s.sim_steps += 1;
-      s.it_hist[(sh.it0 < 8 ? sh.it0 : 8) - 1] += 1;
-      s.it_hist[(sh.it1 < 8 ? sh.it1 : 8) - 1] += 1;
+      s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;
+      s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;
       if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
       if (s.t > P.init_time) {  // clientCFD.pde:39-47
         s.callLearn--;
@@ -510,8 +510,13 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
     const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 2;  // advdif_v2
-    const size_t rings = (size_t)afc::gs_lds_floats(sf.m) + 64;  // mg_up_smooth
-    env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * (tile > rings ? tile : rings);
+    const size_t rings = (size_t)afc::gs_lds_floats(sf.m) + 64;  // mg_up_smooth (single-wave march, kept for A/B)
+    size_t fl = tile > rings ? tile : rings;
+    // multi-wave smoother: both rings of every level live in the same region; with four workgroups per CU a
+    // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)
+    const size_t mw_budget = (36 * 1024 + 512) / sizeof(float);
+    if (fl < mw_budget) fl = mw_budget;
+    env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * fl;
   }
 
   int rc = AFC_OK;
@@ -543,6 +548,13 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           const float sumd = lw + le + ls + ln;
           D.invtab[3 * rc + cc] = (sumd > 1e-5f) ? -1.f / sumd : 1.f;
         }
+      {  // strip height of the multi-wave smoother: the largest H <= 63 whose two rings fit the LDS region
+        const int budget = (int)(env->lds_bytes / sizeof(float));
+        int H = L.n - 2 + 3;  // never more lanes than rows (+ the three shifted ones)
+        if (H > 62) H = 62;  // lane 0 re-plays the row above the strip, lane H+1 holds the coefficients of the row below
+        while (H > 4 && afc::mw_lds_floats(L.m, H) > budget) --H;
+        D.mw_H = H;
+      }
       D.sp_i0 = 1 << 30;
       D.sp_i1 = -1;
       for (int i = 1; i < L.n - 1; ++i)

@@ -126,12 +126,14 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
   const bool lane_on = (j0 <= m - 2);
   const float nu = uni(P.nu), dt = uni(P.dt);
   const bool same = (bx == sx) && (by == sy);
+  const int xdbg = uni(P.dbg);  // diagnostics: 16 = no stencil arithmetic, 32 = no global stores, 64 = no tile loads
   for (int a = 1; a <= n - 2; a += R) {
     // ---- stage rows a-2 .. a+R+1 of src into LDS (flat, coalesced float2) ----
     const int t0 = (a - 2) * m;                    // flat index of tile row 0
     const int lo = t0 < 0 ? 0 : t0;
     const int hi = ((a + R + 2) * m < N) ? (a + R + 2) * m : N;
     lds_barrier();  // previous block's readers are done
+    if (!(xdbg & 64))
     for (int q = lo + 2 * threadIdx.x; q < hi; q += 2 * kThreads) {
       const float2 vx = *reinterpret_cast<const float2 *>(sx + q);
       const float2 vy = *reinterpret_cast<const float2 *>(sy + q);
@@ -189,6 +191,11 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
 #define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
           const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
+          if (xdbg & 16) {
+            oxv[e] = cc.x + bxv[e];
+            oyv[e] = cc.y + byv[e];
+            continue;
+          }
           f2 fW;
           if (ii == 0) {
             const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
@@ -213,7 +220,9 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           fS2 = fN;
 #undef XY
         }
-        if (full) {
+        if (xdbg & 32) {
+          if (oxv[0] == 12345.678f) dx[i * m + j0] = oyv[0];  // keeps the values live, never taken
+        } else if (full) {
           __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
           __builtin_memcpy(dy + i * m + j0, oyv, sizeof(float) * C);
         } else {
@@ -483,6 +492,7 @@ struct UpGeom {
   int n, m, n_, m_, mc, PW, CPR;
   float *rr, *dr;
   DescU du;
+  int NR = kRing;        // rows in the LDS rings (24 for the strip march, H + 6 for the multi-wave smoother)
   bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
   bool update_x = true;  // false: replay that only materialises r
 };
@@ -524,7 +534,7 @@ __device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, in
 __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int g, int c4, const FillIn &in, bool sp) {
   const int m = U.m, n_ = U.n_, m_ = U.m_, CPR = U.CPR;
   const int j = 1 + 4 * c4;
-  const int sl = (g % kRing) * U.PW + j;
+  const int sl = (g % U.NR) * U.PW + j;
   F4 rv = in.r, dv;
 #pragma unroll
   for (int e = 0; e < 4; ++e) dv.v[e] = 0.f;
@@ -604,7 +614,7 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
   float *rr = U.rr, *dr = U.dr;
   const int j = 1 + 4 * c4, kk = g * m + j;
   const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
-  const int sl = (g % kRing) * PW + j;
+  const int sl = (g % U.NR) * PW + j;
   float dp[4] = {0.f, 0.f, 0.f, 0.f};
   if (HASC) {
     dp[0] = in.a1;
@@ -619,7 +629,7 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
   if (c4 == CPR - 1) d6[5] = d6[4];
   F4 xn;
   if (need_r) {
-    const float *dwp = dr + (gw % kRing) * PW + j, *dep = dr + (ge % kRing) * PW + j;
+    const float *dwp = dr + (gw % U.NR) * PW + j, *dep = dr + (ge % U.NR) * PW + j;
     F4 lw, le, ls;
     float ln4;
     if (sp) {
@@ -847,6 +857,331 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     float xg = F.x[(GI) * m + (GJ)];             \
     if (HASC) xg = xg + dp;                      \
     F.x[(GI) * m + (GJ)] = xg + d;               \
+  }
+            if (gi0) GHOST_UPD(0, j)
+            if (gi1) GHOST_UPD(n - 1, j)
+            if (gj0) GHOST_UPD(g, 0)
+            if (gj1) GHOST_UPD(g, m - 1)
+            if (gi0 && gj0) GHOST_UPD(0, 0)
+            if (gi0 && gj1) GHOST_UPD(0, m - 1)
+            if (gi1 && gj0) GHOST_UPD(n - 1, 0)
+            if (gi1 && gj1) GHOST_UPD(n - 1, m - 1)
+#undef GHOST_UPD
+          }
+        }
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
+    if (need_r) pf.mark(PF_INC0);
+  }
+  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
+  if (need_r && rmode != 2) {
+    *rr_out = uni((float)block_sum_d(rr_part, sm));
+    *linf_out = uni(block_max_f(linf, sm));
+    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+  }
+}
+
+// =============================================================================================
+// Multi-wave hyperplane smoother: MG.smooth(4) (MG.pde:79-92) with ALL FOUR WAVES of the workgroup.
+//
+// Wave k runs sweep k; lane l (1..H) of wave k owns row i = I0 - k - 1 + l of a strip of H rows (the strip of
+// sweep k is shifted up by k rows, so sweep k never needs a row its predecessor has not finished), lane 0 re-plays
+// row I0 - k - 1, which the previous strip finished, so that every real lane finds d[i-1][j] in lane-1.
+// At global step tau the lane is at column j = tau - l - S*k + 1.  The four neighbours of cell (i,j) in sweep k:
+//   d[i-1][j] (sweep k)   computed one step earlier by lane l-1  -> DPP wave_shr:1
+//   d[i][j-1] (sweep k)   computed one step earlier by this lane -> register
+//   d[i+1][j] (sweep k-1) | both were written to the LDS array D by wave k-1 exactly S steps earlier (k == 0: d0 =
+//   d[i][j+1] (sweep k-1) | r*inv left there by the fill) and are overwritten by this very sweep one step LATER
+// which is the order the sequential loops of the reference see, so every cell gets the reference's bits.
+// Steps are grouped in chunks of 4 with ONE LDS barrier per chunk: a chunk reads its operands from LDS one chunk
+// ahead, computes 4 steps in registers and writes its 4 results; S = 8 guarantees that what a chunk prefetches was
+// written at least one barrier earlier (4q+e+4-S <= 4q-1) and that nothing it still needs has been overwritten.
+// D and R (r after the prolongation increment) are rings of NR = H + 6 full-width rows; r is read-only here.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMwS = 8;
+constexpr int kMwGuardLo = 96, kMwGuardMid = 160;  // lanes outside their row read (and ignore) whatever lies there
+
+__device__ __host__ __forceinline__ int mw_lds_floats(int m, int H) {
+  return kMwGuardLo + 2 * ((H + 6) * m + kMwGuardMid) + 64;
+}
+
+__device__ __forceinline__ float lane_prev(float v) {  // the value lane-1 holds (whole wave); lane 0 gets 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_next(float v) {  // the value lane+1 holds (whole wave); lane 63 gets 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
+
+// dst = lane 0 ? b : a, as one v_cndmask on a constant mask (kept opaque: written as a C select the compiler
+// predicates the whole update on it and pays an exec-mask branch per step)
+__device__ __forceinline__ float sel_lane0(float a, float b) {
+  float r;
+  const unsigned long long mk = 1ull;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mk));
+  return r;
+}
+
+// Not inlined on purpose: the three instantiations get their own register allocation (50 / 68 / 120 VGPRs) instead
+// of inflating the live ranges of the phases around them.
+template <bool FAST, bool ZB>
+__device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *Dg, float *dummyg, int NR, int I0,
+                                          int Lmax) {
+  const lds_f *R = (const lds_f *)Rg;
+  lds_f *D = (lds_f *)Dg;
+  lds_f *dummy = (lds_f *)dummyg;
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = I0 - k - 1 + lane;
+  const bool rowin = (i >= 1) && (i <= n_);
+  const bool is0 = (lane == 0);
+  const bool real = rowin && !is0 && (lane <= Lmax);
+  const unsigned m_on = (real || (rowin && is0)) ? (unsigned)m_ : 0u;  // columns 1..m_on produce a value
+  const unsigned m_wr = real ? (unsigned)m_ : 0u;                     // ... and are stored
+  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);
+  const int so = (ic % NR) * m;
+  const int se = is0 ? so : ((ic + 1) % NR) * m;  // lane 0 fetches its own (finished) row through the east stream
+  const int jo = 1 - lane - kMwS * k;
+  const LevelDesc &Dsc = *L.desc;
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
+  if (FAST) {
+    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
+    iv0 = Dsc.invtab[3 * rc + 0];
+    iv1 = Dsc.invtab[3 * rc + 1];
+    iv2 = Dsc.invtab[3 * rc + 2];
+  }
+  const float cu = uni(Dsc.cu);
+  const int T = (m_ + Lmax + 3 * kMwS + 3) & ~3;
+  const lds_f *pR = R + so + jo, *pE = D + se + jo, *pN = D + so + jo + 1;
+  lds_f *pW = D + so + jo;
+  lds_f *dmy = dummy + lane;
+  float cR[4], cE[4], cN[4], nR[4], nE[4], nN[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cR[e] = pR[e];
+    cE[e] = pE[e];
+    cN[e] = pN[e];
+  }
+  // coefficients of the strips that touch a body: four columns per 16-byte load, one chunk ahead.  The east face
+  // lx[i+1][j] is the west face of the row below, i.e. what lane+1 (one column behind) holds: no load for it.
+  F4 c_lw, c_ls, c_iv, x_lw, x_ls, x_iv;
+  float c_ln4 = 0.f, x_ln4 = 0.f;
+  const int icf = i < 0 ? 0 : (i > n_ + 1 ? n_ + 1 : i);  // every lane loads its own row (also the one below the strip)
+  const int cbase = icf * m + jo;
+#define MW_COEF(TAU, lw_, ls_, iv_, ln4_) \
+  {                                       \
+    int kk_ = cbase + (TAU);              \
+    kk_ = kk_ < 0 ? 0 : kk_;              \
+    lw_ = load4u(L.lx + kk_);             \
+    ls_ = load4u(L.ly + kk_);             \
+    iv_ = load4u(L.inv + kk_);            \
+    ln4_ = L.ly[kk_ + 4];                 \
+  }
+  if (!FAST) MW_COEF(0, x_lw, x_ls, x_iv, x_ln4)
+  float cur = 0.f;
+  for (int tau0 = 0; tau0 < T; tau0 += 4) {
+    // operands of the next chunk: written by the previous sweep at least one barrier ago (S = 8)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      nR[e] = pR[tau0 + 4 + e];
+      nE[e] = pE[tau0 + 4 + e];
+      nN[e] = pN[tau0 + 4 + e];
+    }
+    float le4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!FAST) {
+      c_lw = x_lw;
+      c_ls = x_ls;
+      c_iv = x_iv;
+      c_ln4 = x_ln4;
+      MW_COEF(tau0 + 4, x_lw, x_ls, x_iv, x_ln4)
+      le4[0] = lane_next(c_lw.v[1]);
+      le4[1] = lane_next(c_lw.v[2]);
+      le4[2] = lane_next(c_lw.v[3]);
+      le4[3] = lane_next(x_lw.v[0]);
+    }
+    const int jb = tau0 + jo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lw, le, ls, ln, iv;
+      if (FAST) {  // out-of-domain neighbours read as d = 0, so a boundary face may keep the uniform coefficient
+        lw = le = ls = ln = cu;
+        iv = iv0;
+        if (ZB) {
+          const int j = jb + e;
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);
+        }
+      } else {
+        lw = c_lw.v[e];
+        le = le4[e];
+        ls = c_ls.v[e];
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;
+        iv = c_iv.v[e];
+      }
+      const float prev = cur;
+      const float dW = lane_prev(prev);
+      const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv;  // MG.pde:84-88
+      const float v2 = sel_lane0(v, cE[e]);
+      cur = ((unsigned)(jb + e - 1) < m_on) ? v2 : 0.f;
+      lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0 + e) : dmy;
+      *w = cur;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cR[e] = nR[e];
+      cE[e] = nE[e];
+      cN[e] = nN[e];
+    }
+  }
+#undef MW_COEF
+}
+
+// One call = everything a level does on the way up, like mg_up_smooth, with the multi-wave smoother: strips of
+// H rows (H = LevelDesc.mw_H, chosen on the host so that both rings fit the workgroup's LDS).
+__device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                       float *rr_out, float *linf_out, Prof &pf, float *xsum_out = nullptr,
+                                       const int rmode = 0) {
+  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
+  const LevelDesc &D = *F.desc;
+  const int H = uni(D.mw_H), NR = H + 6;
+  float *dr = lds + kMwGuardLo, *rr = dr + NR * m + kMwGuardMid, *dummy = rr + NR * m + kMwGuardMid;
+  const int tid = threadIdx.x;
+  const int mc = Cc.m;
+  const int PW = m;
+  const int rstep = kThreads / m, cstep = kThreads - rstep * m;
+  const int r0 = tid / m, c0 = tid - r0 * m;
+  double rr_part = 0, xs_part = 0;
+  float linf = 0.f;
+  const int CPR = m_ >> 2;
+  const bool chunked = ((m_ & 3) == 0);
+  const DescU du = desc_u(D);
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
+  U.NR = NR;
+  U.store_r = (rmode != 1);
+  U.update_x = (rmode != 2);
+  // a thread keeps its 4-column chunk and walks down the rows of its group: no division in the strip loops
+  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
+  const bool grp_on = chunked && (rg < ngrp);
+  __syncthreads();
+  int loaded = 0;
+  for (int I0 = 1; I0 - 3 <= n_; I0 += H) {
+    const int hi = I0 + H;
+    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
+    if (chunked) {
+      if (grp_on)
+        for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+          const FillIn in = fill_load(U, HASC, g, c4);
+          fill_apply(U, HASC, g, c4, in, sp_fill);
+        }
+    } else {
+      int g = loaded + 1 + r0, j = c0;
+      while (g <= hi) {
+        float rv = 0.f, dv = 0.f;
+        if (g <= n_ && j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          rv = F.r[kk];
+          float lw, le, ls, ln, iv;
+          if (sp_fill) {
+            lw = F.lx[kk];
+            le = F.lx[kk + m];
+            ls = F.ly[kk];
+            ln = F.ly[kk + 1];
+            iv = F.inv[kk];
+          } else {
+            coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+          }
+          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+            const float dc = prolong_at(Cc.x, mc, g, j, n_, m_);
+            const float dw = prolong_at(Cc.x, mc, g - 1, j, n_, m_), de = prolong_at(Cc.x, mc, g + 1, j, n_, m_);
+            const float ds = prolong_at(Cc.x, mc, g, j - 1, n_, m_), dn = prolong_at(Cc.x, mc, g, j + 1, n_, m_);
+            const float diag = -(lw + le + ls + ln);
+            rv = rv - (dc * diag + dw * lw + de * le + ds * ls + dn * ln);
+          }
+          dv = rv * iv;  // MG.pde:80
+        }
+        const int sl = (g % NR) * PW + j;
+        rr[sl] = rv;
+        dr[sl] = dv;
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    loaded = hi;
+    lds_barrier();
+    if (need_r) pf.mark(PF_UP0);
+    {
+      const int lm = n_ - I0 + 4, Lmax = lm < H ? lm : H;
+      const bool special = (hi >= du.sp_i0) && (I0 - 4 <= du.sp_i1);
+      if (special)
+        gs_multiwave<false, true>(F, rr, dr, dummy, NR, I0, Lmax);
+      else if (du.zb)
+        gs_multiwave<true, true>(F, rr, dr, dummy, NR, I0, Lmax);
+      else
+        gs_multiwave<true, false>(F, rr, dr, dummy, NR, I0, Lmax);
+    }
+    if (need_r) pf.mark(PF_GS0);
+    // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
+    const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + H - 4 >= n_) ? n_ : I0 + H - 5;
+    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
+    if (chunked) {
+      if (grp_on)
+        for (int g = e0 + rg; g <= e1; g += ngrp) {
+          const ExitIn in = exit_load(U, HASC, g, c4);
+          exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+        }
+    } else {
+      int g = e0 + r0, j = c0;
+      while (g <= e1) {
+        if (j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+          const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
+          const int sl = (g % NR) * PW;
+          const float d = dr[sl + j];
+          if (need_r) {
+            const float dW = dr[(gw % NR) * PW + j], dE = dr[(ge % NR) * PW + j];
+            const float dS = dr[sl + js], dN = dr[sl + jn];
+            float lw, le, ls, ln, iv;
+            if (sp_exit) {
+              lw = F.lx[kk];
+              le = F.lx[kk + m];
+              ls = F.ly[kk];
+              ln = F.ly[kk + 1];
+            } else {
+              coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+            }
+            const float diag = -(lw + le + ls + ln);
+            const float rn = rr[sl + j] - (d * diag + dW * lw + dE * le + dS * ls + dN * ln);  // MG.pde:96
+            F.r[kk] = rn;
+            const float pr = rn * rn;
+            rr_part += (double)pr;
+            linf = jmax(linf, jabs(rn));
+          }
+          float xo = F.x[kk];
+          if (HASC) xo = xo + prolong_at(Cc.x, mc, g, j, n_, m_);
+          const float xnew = xo + d;
+          F.x[kk] = xnew;
+          if (need_r) xs_part += (double)xnew;
+          const bool gi0 = (g == 1), gi1 = (g == n_), gj0 = (j == 1), gj1 = (j == m_);
+          if (gi0 | gi1 | gj0 | gj1) {
+            const float dp = HASC ? prolong_at(Cc.x, mc, g, j, n_, m_) : 0.f;
+#define GHOST_UPD(GI, GJ)            \
+  {                                  \
+    float xg = F.x[(GI) * m + (GJ)]; \
+    if (HASC) xg = xg + dp;          \
+    F.x[(GI) * m + (GJ)] = xg + d;   \
   }
             if (gi0) GHOST_UPD(0, j)
             if (gi1) GHOST_UPD(n - 1, j)
@@ -1108,7 +1443,10 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     {
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
-      mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      if (P.dbg & 4)
+        mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      else
+        mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
     }
     for (int l = kc - 1; l >= 0; --l) {
@@ -1117,10 +1455,16 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(P.dbg & 2);
-      mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      if (P.dbg & 4)
+        mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else
+        mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
         float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
-        mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        if (P.dbg & 4)
+          mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        else
+          mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
       }
       pf.mark(l == 0 ? PF_RR : (16 + l));
     }
