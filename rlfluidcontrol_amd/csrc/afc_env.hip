@@ -554,6 +554,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
         if (H > 62) H = 62;  // lane 0 re-plays the row above the strip, lane H+1 holds the coefficients of the row below
         while (H > 4 && afc::mw_lds_floats(L.m, H) > budget) --H;
         D.mw_H = H;
+        D.dbg_copy = cfg->reserved[0];
       }
       D.sp_i0 = 1 << 30;
       D.sp_i1 = -1;

@@ -45,6 +45,7 @@ struct LevelDesc {
   int zero_bnd;
   float invtab[9];
   int sp_i0, sp_i1;
+  int dbg_copy;      // StepParams.dbg, reachable from an Lv (diagnostic switches)
   int mw_H;          // strip height of the multi-wave smoother on this level (rows per sweep per strip, <= 63)
 };
 

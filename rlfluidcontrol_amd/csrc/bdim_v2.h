@@ -934,7 +934,7 @@ __device__ __forceinline__ float sel_lane0(float a, float b) {
 // of inflating the live ranges of the phases around them.
 template <bool FAST, bool ZB>
 __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *Dg, float *dummyg, int NR, int I0,
-                                          int Lmax) {
+                                          int Lmax, int xdbg = 0) {
   const lds_f *R = (const lds_f *)Rg;
   lds_f *D = (lds_f *)Dg;
   lds_f *dummy = (lds_f *)dummyg;
@@ -1033,7 +1033,7 @@ __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *D
       lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0 + e) : dmy;
       *w = cur;
     }
-    lds_barrier();
+    if (!(xdbg & 128)) lds_barrier();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       cR[e] = nR[e];
@@ -1124,12 +1124,14 @@ __device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &C
     {
       const int lm = n_ - I0 + 4, Lmax = lm < H ? lm : H;
       const bool special = (hi >= du.sp_i0) && (I0 - 4 <= du.sp_i1);
+      const int xd = uni(F.desc->dbg_copy);
       if (special)
-        gs_multiwave<false, true>(F, rr, dr, dummy, NR, I0, Lmax);
+        gs_multiwave<false, true>(F, rr, dr, dummy, NR, I0, Lmax, xd);
       else if (du.zb)
-        gs_multiwave<true, true>(F, rr, dr, dummy, NR, I0, Lmax);
+        gs_multiwave<true, true>(F, rr, dr, dummy, NR, I0, Lmax, xd);
       else
-        gs_multiwave<true, false>(F, rr, dr, dummy, NR, I0, Lmax);
+        gs_multiwave<true, false>(F, rr, dr, dummy, NR, I0, Lmax, xd);
+      if (xd & 128) lds_barrier();
     }
     if (need_r) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
@@ -1443,7 +1445,7 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     {
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
-      if (P.dbg & 4)
+      if (!(P.dbg & 4))
         mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       else
         mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
@@ -1455,13 +1457,13 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(P.dbg & 2);
-      if (P.dbg & 4)
+      if (!(P.dbg & 4))
         mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else
         mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
         float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
-        if (P.dbg & 4)
+        if (!(P.dbg & 4))
           mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
@@ -1520,8 +1522,14 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
       un.v[e] = u4.v[e] + cx4.v[e] * (gx * -1.f);                // VectorField.pde:138
       vn.v[e] = v4.v[e] + cy4.v[e] * (gy * -1.f);
     }
-    store4u(vx + k, un);
-    store4u(vy + k, vn);
+    // The corrector's projected field C is only an intermediate of the Heun average: after this pass nothing reads
+    // its interior again (the next step's advection overwrites every interior cell before use; the wall columns of
+    // A are formed from registers right here).  Only rows 1 and n-2 are still read: by setBC's row copies and outflow
+    // mean and by the 4-row fix-up below.
+    if (!HEUN || g == 1 || g == n_) {
+      store4u(vx + k, un);
+      store4u(vy + k, vn);
+    }
     if (HEUN) {  // cells on the rows setBC rewrites (0, 1, n-2, n-1) are redone below
       const F4 b4 = load4u(ox + k), d4 = load4u(oy + k);
       F4 a4, e4;
