@@ -65,6 +65,16 @@ __device__ __forceinline__ DescU desc_u(const LevelDesc &D) {
   return u;
 }
 
+struct F4 {
+  float v[4];
+};
+__device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byte load (global_load_dwordx4)
+  F4 r;
+  __builtin_memcpy(&r, p, 16);
+  return r;
+}
+__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
+
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
 // flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
@@ -311,16 +321,6 @@ __device__ __forceinline__ float lane_minus16(float v, int lane) {
   auto b = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);  // b[0] = [r0,r0,r1,r1]
   return __builtin_bit_cast(float, ((lane >> 4) == 3) ? a[0] : b[0]);   //      -> [ *,r0,r1,r2]
 }
-
-struct F4 {
-  float v[4];
-};
-__device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byte load (global_load_dwordx4)
-  F4 r;
-  __builtin_memcpy(&r, p, 16);
-  return r;
-}
-__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
 
 // LDS layout used by the smoother (floats, PW = m + kPad):
 //   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][carry 4*PW][kPad][zero row PW][kPad][dummy row PW]
@@ -732,6 +732,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
+  // a thread keeps its 4-column chunk and walks down the rows of its group: no integer division in the strip loops
+  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
+  const bool grp_on = chunked && (rg < ngrp);
   __syncthreads();
   // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
   // (the region is shared with the other phases' tiles, so this is redone on every call)
@@ -744,12 +747,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
     if (chunked) {
       // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
-      const int nrow = hi - loaded;
-      for (int q = tid; q < nrow * CPR; q += kThreads) {
-        const int t = q / CPR, c4 = q - t * CPR;
-        const FillIn in = fill_load(U, HASC, loaded + 1 + t, c4);
-        fill_apply(U, HASC, loaded + 1 + t, c4, in, sp_fill);
-      }
+      if (grp_on)
+        for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+          const FillIn in = fill_load(U, HASC, g, c4);
+          fill_apply(U, HASC, g, c4, in, sp_fill);
+        }
     } else
     {
       int g = loaded + 1 + r0, j = c0;
@@ -808,12 +810,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
     const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
     if (chunked) {
-      const int nrow = e1 - e0 + 1;
-      for (int q = tid; q < nrow * CPR; q += kThreads) {
-        const int t = q / CPR, c4 = q - t * CPR;
-        const ExitIn in = exit_load(U, HASC, e0 + t, c4);
-        exit_apply(U, HASC, need_r, e0 + t, c4, in, sp_exit, rr_part, xs_part, linf);
-      }
+      if (grp_on)
+        for (int g = e0 + rg; g <= e1; g += ngrp) {
+          const ExitIn in = exit_load(U, HASC, g, c4);
+          exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+        }
     } else
     {
       int g = e0 + r0, j = c0;
