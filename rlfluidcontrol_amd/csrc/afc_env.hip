@@ -61,7 +61,9 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
   float pshift = G(P.sc)[e].p_shift;
+  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
   step_dispatch<CPL>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
+  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P);
   if (threadIdx.x == 0) {
     EnvScalars &s = G(P.sc)[e];
     s.p_shift = pshift;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     s_stop = 0;
   }
   __syncthreads();
+  if (CPL != 0) afc::gate_acquire(P);
   const float xi1_m = afc::uni(s.xi1_m), xi2_m = afc::uni(s.xi2_m);
   float pshift = s.p_shift;
   int steps = 0;
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     __syncthreads();
     if (s_stop) break;
   }
+  if (CPL != 0) afc::gate_release(P);
   if (threadIdx.x == 0) {
     s.p_shift = pshift;
     G(P.sc)[e] = s;
@@ -613,6 +617,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_alloc(env, &env->d_u8, E);
   if (!rc) rc = dev_alloc(env, &env->d_i32, E * 2);
   if (!rc) rc = dev_alloc(env, &env->d_P, (size_t)1);
+  if (!rc) rc = dev_alloc(env, &P.gate, (size_t)256);
+  if (!rc && hipMemset(G(P.gate), 0, 256 * sizeof(int)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  P.gate_limit = (cfg->reserved[0] >> 16) & 15;  // experiment switch (dbg bits 16-19)
   if (!rc) rc = dev_alloc(env, &env->d_stamps, (size_t)32);
   if (!rc && hipMemset(env->d_stamps, 0, 32 * sizeof(long long)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (rc) {

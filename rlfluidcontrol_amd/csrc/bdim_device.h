@@ -92,6 +92,8 @@ struct StepParams {
   AFC_AS1 float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
   AFC_AS1 EnvScalars *sc;
   AFC_AS1 long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
+  AFC_AS1 int *gate;          // [256] streaming-phase tokens per group of workgroups that share a CU (experiment)
+  int gate_limit;             // 0 = off; else at most this many workgroups of a group are in a streaming phase
   // episode constants
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
@@ -140,6 +142,27 @@ struct Prof {
 };
 enum { PF_ADVDIF = 0, PF_FORCING, PF_SETBC, PF_RESID, PF_DOWN0, PF_COARSE_DOWN, PF_COARSE_GS, PF_COARSE_UP, PF_UP0,
        PF_GS0, PF_INC0, PF_RR, PF_PROJECT, PF_HEUN, PF_COUNT };
+
+// ---- streaming-phase gate (experiment): workgroups b, b+256, b+512, ... tend to share a CU; at most gate_limit of them
+// may be in the HBM-heavy part of the step (projection tail .. solve head) at a time, so that the latency-bound
+// multigrid part of their CU mates runs beside it instead of beside more multigrid.  Speed only, never correctness.
+__device__ inline void gate_acquire(const StepParams &P) {
+  if (P.gate_limit <= 0) return;
+  if (threadIdx.x == 0) {
+    int *g = G(P.gate) + (blockIdx.x & 255);
+    while (true) {
+      const int v = __hip_atomic_fetch_add(g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v < P.gate_limit) break;
+      __hip_atomic_fetch_add(g, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  __syncthreads();
+}
+__device__ inline void gate_release(const StepParams &P) {
+  if (P.gate_limit <= 0) return;
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(G(P.gate) + (blockIdx.x & 255), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- workgroup reductions (fixed tree order => deterministic) ----
 __device__ inline double block_sum_d(double v, double *sm) {

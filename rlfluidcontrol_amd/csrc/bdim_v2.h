@@ -17,6 +17,9 @@ namespace afc {
 // keep __syncthreads().
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
+typedef __attribute__((address_space(3))) int lds_i;
+
 // Values that are the same in every lane but reached the wave through vector loads (the level
 // table sits in global memory) occupy a VGPR each and get spilled around the register-hungry
 // loops; readfirstlane moves them to SGPRs.
@@ -910,7 +913,7 @@ constexpr int kMwS = 8;
 constexpr int kMwGuardLo = 96, kMwGuardMid = 160;  // lanes outside their row read (and ignore) whatever lies there
 
 __device__ __host__ __forceinline__ int mw_lds_floats(int m, int H) {
-  return kMwGuardLo + 2 * ((H + 6) * m + kMwGuardMid) + 64;
+  return kMwGuardLo + 2 * ((H + 6) * m + kMwGuardMid) + 64 + 8;
 }
 
 __device__ __forceinline__ float lane_prev(float v) {  // the value lane-1 holds (whole wave); lane 0 gets 0
@@ -920,27 +923,37 @@ __device__ __forceinline__ float lane_next(float v) {  // the value lane+1 holds
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
-typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
 
-// dst = lane 0 ? b : a, as one v_cndmask on a constant mask (kept opaque: written as a C select the compiler
-// predicates the whole update on it and pays an exec-mask branch per step)
-__device__ __forceinline__ float sel_lane0(float a, float b) {
+// dst = (lane is a re-play lane) ? b : a, as one v_cndmask on a constant lane mask (kept opaque: written as a C
+// select the compiler predicates the whole update on it and pays an exec-mask branch per step)
+__device__ __forceinline__ float sel_mask(float a, float b, unsigned long long mk) {
   float r;
-  const unsigned long long mk = 1ull;
   asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mk));
   return r;
 }
 
-// Not inlined on purpose: the three instantiations get their own register allocation (50 / 68 / 120 VGPRs) instead
-// of inflating the live ranges of the phases around them.
-template <bool FAST, bool ZB>
+// PER = sweeps per wave.  PER 1: wave k = sweep k, up to 62 rows per strip.  PER 2: waves 0 and 1 carry two sweeps
+// each (lanes 0-31 / 32-63), up to 30 rows per strip -- the form for the finest level, whose strips are LDS-bound
+// to ~28 rows: half the instruction streams for the same step count.  Waves wait for each other through progress
+// words in LDS (a wave publishes the number of the chunk it has finished; the next sweep's wave checks it before it
+// prefetches), not through workgroup barriers: LDS operations of one wave execute in order, so a consumer that sees
+// the progress word also sees the data written before it.
+// Not inlined on purpose: every instantiation gets its own register allocation instead of inflating the live ranges
+// of the phases around it.
+template <bool FAST, bool ZB, int PER>
 __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *Dg, float *dummyg, int NR, int I0,
-                                          int Lmax, int xdbg = 0) {
+                                          int Lmax, int gbase) {
+  const int wave = threadIdx.x >> 6;
+  if (PER == 2 && wave >= 2) return;
   const lds_f *R = (const lds_f *)Rg;
   lds_f *D = (lds_f *)Dg;
   lds_f *dummy = (lds_f *)dummyg;
+  volatile lds_i *prog = (volatile lds_i *)(dummy + 64);  // [4] progress words
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
-  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane64 = threadIdx.x & 63;
+  const int lane = (PER == 2) ? (lane64 & 31) : lane64;
+  const int k = (PER == 2) ? (2 * wave + (lane64 >> 5)) : wave;
+  const unsigned long long replay = (PER == 2) ? 0x100000001ull : 1ull;
   const int i = I0 - k - 1 + lane;
   const bool rowin = (i >= 1) && (i <= n_);
   const bool is0 = (lane == 0);
@@ -949,7 +962,7 @@ __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *D
   const unsigned m_wr = real ? (unsigned)m_ : 0u;                     // ... and are stored
   const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);
   const int so = (ic % NR) * m;
-  const int se = is0 ? so : ((ic + 1) % NR) * m;  // lane 0 fetches its own (finished) row through the east stream
+  const int se = is0 ? so : ((ic + 1) % NR) * m;  // re-play lanes fetch their own (finished) row through the east stream
   const int jo = 1 - lane - kMwS * k;
   const LevelDesc &Dsc = *L.desc;
   float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
@@ -960,21 +973,21 @@ __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *D
     iv2 = Dsc.invtab[3 * rc + 2];
   }
   const float cu = uni(Dsc.cu);
-  const int T = (m_ + Lmax + 3 * kMwS + 3) & ~3;
+  const int T = (m_ + Lmax + 3 * kMwS + 7) & ~7;  // two chunks per loop iteration
   const lds_f *pR = R + so + jo, *pE = D + se + jo, *pN = D + so + jo + 1;
   lds_f *pW = D + so + jo;
-  lds_f *dmy = dummy + lane;
-  float cR[4], cE[4], cN[4], nR[4], nE[4], nN[4];
+  lds_f *dmy = dummy + lane64;
+  float aR[4], aE[4], aN[4], bR[4], bE[4], bN[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    cR[e] = pR[e];
-    cE[e] = pE[e];
-    cN[e] = pN[e];
+    aR[e] = pR[e];
+    aE[e] = pE[e];
+    aN[e] = pN[e];
   }
   // coefficients of the strips that touch a body: four columns per 16-byte load, one chunk ahead.  The east face
   // lx[i+1][j] is the west face of the row below, i.e. what lane+1 (one column behind) holds: no load for it.
-  F4 c_lw, c_ls, c_iv, x_lw, x_ls, x_iv;
-  float c_ln4 = 0.f, x_ln4 = 0.f;
+  F4 a_lw, a_ls, a_iv, b_lw, b_ls, b_iv;
+  float a_ln4 = 0.f, b_ln4 = 0.f;
   const int icf = i < 0 ? 0 : (i > n_ + 1 ? n_ + 1 : i);  // every lane loads its own row (also the one below the strip)
   const int cbase = icf * m + jo;
 #define MW_COEF(TAU, lw_, ls_, iv_, ln4_) \
@@ -986,62 +999,73 @@ __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *D
     iv_ = load4u(L.inv + kk_);            \
     ln4_ = L.ly[kk_ + 4];                 \
   }
-  if (!FAST) MW_COEF(0, x_lw, x_ls, x_iv, x_ln4)
+  if (!FAST) MW_COEF(0, a_lw, a_ls, a_iv, a_ln4)
   float cur = 0.f;
-  for (int tau0 = 0; tau0 < T; tau0 += 4) {
-    // operands of the next chunk: written by the previous sweep at least one barrier ago (S = 8)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      nR[e] = pR[tau0 + 4 + e];
-      nE[e] = pE[tau0 + 4 + e];
-      nN[e] = pN[tau0 + 4 + e];
-    }
-    float le4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!FAST) {
-      c_lw = x_lw;
-      c_ls = x_ls;
-      c_iv = x_iv;
-      c_ln4 = x_ln4;
-      MW_COEF(tau0 + 4, x_lw, x_ls, x_iv, x_ln4)
-      le4[0] = lane_next(c_lw.v[1]);
-      le4[1] = lane_next(c_lw.v[2]);
-      le4[2] = lane_next(c_lw.v[3]);
-      le4[3] = lane_next(x_lw.v[0]);
-    }
-    const int jb = tau0 + jo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float lw, le, ls, ln, iv;
-      if (FAST) {  // out-of-domain neighbours read as d = 0, so a boundary face may keep the uniform coefficient
-        lw = le = ls = ln = cu;
-        iv = iv0;
-        if (ZB) {
-          const int j = jb + e;
-          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);
-        }
-      } else {
-        lw = c_lw.v[e];
-        le = le4[e];
-        ls = c_ls.v[e];
-        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;
-        iv = c_iv.v[e];
-      }
-      const float prev = cur;
-      const float dW = lane_prev(prev);
-      const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv;  // MG.pde:84-88
-      const float v2 = sel_lane0(v, cE[e]);
-      cur = ((unsigned)(jb + e - 1) < m_on) ? v2 : 0.f;
-      lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0 + e) : dmy;
-      *w = cur;
-    }
-    if (!(xdbg & 128)) lds_barrier();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      cR[e] = nR[e];
-      cE[e] = nE[e];
-      cN[e] = nN[e];
-    }
+  const bool consumer = (wave > 0);
+  volatile lds_i *pprod = prog + (wave > 0 ? wave - 1 : 0);
+  int seen = gbase - 1;
+  if (consumer) __builtin_amdgcn_s_sleep(8);  // start about one chunk behind the producer: its progress word is then
+                                              // normally ahead of what is asked for and nobody spins
+  // one chunk: prefetch the operands of the next chunk into (nR,nE,nN / n_*), run 4 steps on (cR,cE,cN / c_*)
+#define MW_CHUNK(TAU0, cR, cE, cN, nR, nE, nN, c_lw, c_ls, c_iv, c_ln4, n_lw, n_ls, n_iv, n_ln4)                  \
+  {                                                                                                               \
+    const int tau0_ = (TAU0);                                                                                     \
+    const int q_ = tau0_ >> 2;                                                                                    \
+    if (consumer && q_ >= 1) { /* the previous sweep must have finished chunk q-1 (S = 8) */                      \
+      const int need_ = gbase + q_ - 1;                                                                           \
+      while (seen < need_) {                                                                                      \
+        __builtin_amdgcn_s_sleep(1);                                                                              \
+        seen = *pprod;                                                                                            \
+      }                                                                                                           \
+    }                                                                                                             \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+      nR[e] = pR[tau0_ + 4 + e];                                                                                  \
+      nE[e] = pE[tau0_ + 4 + e];                                                                                  \
+      nN[e] = pN[tau0_ + 4 + e];                                                                                  \
+    }                                                                                                             \
+    if (consumer) seen = *pprod; /* for the next chunk: usually already far enough */                             \
+    float le4[4] = {0.f, 0.f, 0.f, 0.f};                                                                          \
+    if (!FAST) {                                                                                                  \
+      MW_COEF(tau0_ + 4, n_lw, n_ls, n_iv, n_ln4)                                                                 \
+      le4[0] = lane_next(c_lw.v[1]);                                                                              \
+      le4[1] = lane_next(c_lw.v[2]);                                                                              \
+      le4[2] = lane_next(c_lw.v[3]);                                                                              \
+      le4[3] = lane_next(n_lw.v[0]);                                                                              \
+    }                                                                                                             \
+    const int jb = tau0_ + jo;                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+      float lw, le, ls, ln, iv;                                                                                   \
+      if (FAST) { /* out-of-domain neighbours read as d = 0: a boundary face may keep the uniform coefficient */  \
+        lw = le = ls = ln = cu;                                                                                   \
+        iv = iv0;                                                                                                 \
+        if (ZB) {                                                                                                 \
+          const int j = jb + e;                                                                                   \
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                          \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        lw = c_lw.v[e];                                                                                           \
+        le = le4[e];                                                                                              \
+        ls = c_ls.v[e];                                                                                           \
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                               \
+        iv = c_iv.v[e];                                                                                           \
+      }                                                                                                           \
+      const float prev = cur;                                                                                     \
+      const float dW = lane_prev(prev);                                                                           \
+      const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv; /* MG.pde:84-88 */          \
+      const float v2 = sel_mask(v, cE[e], replay);                                                                \
+      cur = ((unsigned)(jb + e - 1) < m_on) ? v2 : 0.f;                                                           \
+      lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0_ + e) : dmy;                                        \
+      *w = cur;                                                                                                   \
+    }                                                                                                             \
+    asm volatile("" ::: "memory"); /* the progress word goes out after the data */                                \
+    if (lane64 == 0) prog[wave] = gbase + q_;                                                                     \
+    asm volatile("" ::: "memory");                                                                                \
   }
+  for (int tau0 = 0; tau0 < T; tau0 += 8) {
+    MW_CHUNK(tau0, aR, aE, aN, bR, bE, bN, a_lw, a_ls, a_iv, a_ln4, b_lw, b_ls, b_iv, b_ln4)
+    MW_CHUNK(tau0 + 4, bR, bE, bN, aR, aE, aN, b_lw, b_ls, b_iv, b_ln4, a_lw, a_ls, a_iv, a_ln4)
+  }
+#undef MW_CHUNK
 #undef MW_COEF
 }
 
@@ -1072,6 +1096,8 @@ __device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &C
   const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
   const bool grp_on = chunked && (rg < ngrp);
   __syncthreads();
+  int gbase = 0;
+  if (tid < 4) ((lds_i *)(lds_f *)dummy)[64 + tid] = -1;  // progress words of the four waves
   int loaded = 0;
   for (int I0 = 1; I0 - 3 <= n_; I0 += H) {
     const int hi = I0 + H;
@@ -1125,14 +1151,23 @@ __device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &C
     {
       const int lm = n_ - I0 + 4, Lmax = lm < H ? lm : H;
       const bool special = (hi >= du.sp_i0) && (I0 - 4 <= du.sp_i1);
-      const int xd = uni(F.desc->dbg_copy);
-      if (special)
-        gs_multiwave<false, true>(F, rr, dr, dummy, NR, I0, Lmax, xd);
-      else if (du.zb)
-        gs_multiwave<true, true>(F, rr, dr, dummy, NR, I0, Lmax, xd);
-      else
-        gs_multiwave<true, false>(F, rr, dr, dummy, NR, I0, Lmax, xd);
-      if (xd & 128) lds_barrier();
+      gbase += 4096;  // chunk numbers never repeat within a level call, so the progress words need no reset
+      if (H <= 30) {  // two sweeps per wave
+        if (special)
+          gs_multiwave<false, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else if (du.zb)
+          gs_multiwave<true, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else
+          gs_multiwave<true, false, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+      } else {
+        if (special)
+          gs_multiwave<false, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else if (du.zb)
+          gs_multiwave<true, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else
+          gs_multiwave<true, false, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+      }
+      lds_barrier();  // every sweep of the strip is complete
     }
     if (need_r) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
@@ -1413,7 +1448,9 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
 
 // MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
-__device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
+// (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
+// kernels only -- and its 248 VGPRs would halve the occupancy of every kernel that calls it)
+__device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
                                   const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
                                   Prof &pf, float *lds, bool fused_head = true) {
   const int kc = P.nlev - 1;
@@ -1440,6 +1477,7 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
         mg_restrict(F, Cc);
       }
       pf.mark(l == 0 ? PF_DOWN0 : (24 + l));
+      if (l == 0 && iter == 1 && fused_head) gate_release(P);  // the streaming part of this half-step ends here
       if (l == 0 && pf.stop == 3) return iter;
     }
     float rr = 0.f;
@@ -1474,6 +1512,7 @@ __device__ inline int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, c
     if (P.exact_sums) rr = seq_inner(L0, sm);
     if (rr < P.mg_tol) break;
   }
+  if (fused_head) gate_acquire(P);  // projection tail and the next advection follow
   *linf_out = linf;
   *xsum_out = xsum;
   return iter;

@@ -105,9 +105,11 @@ def default_config(**overrides):
     L = load_library()
     cfg = AfcConfig()
     L.afc_default_config(C.byref(cfg))
+    if os.environ.get("AFC_DBG"):  # development: run any program (e.g. the test suite) with experiment switches on
+        cfg.reserved[0] = int(os.environ["AFC_DBG"], 0)
     for k, v in overrides.items():
         if k == "dbg":  # experiment switches (reserved[0])
-            cfg.reserved[0] = int(v)
+            cfg.reserved[0] |= int(v)
             continue
         if not hasattr(cfg, k):
             raise AfcError("unknown config key %r" % k)
