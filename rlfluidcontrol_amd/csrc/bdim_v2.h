@@ -720,6 +720,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   // with rmode 2 in the rare case a second V-cycle needs it); 2 = replay: same d, only r is stored
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   const int PW = m + kPad;
+  const bool mk = need_r || ((F.desc->dbg_copy >> 20) == n);  // diagnostics: phase marks for the level with n rows
   float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
         *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
@@ -795,7 +796,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     }
     loaded = hi;
     lds_barrier();
-    if (need_r) pf.mark(PF_UP0);
+    if (mk) pf.mark(PF_UP0);
     if (tid < 64) {
       const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
@@ -808,7 +809,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();
-    if (need_r) pf.mark(PF_GS0);
+    if (mk) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
     const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
@@ -882,7 +883,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       }
     }
     lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
-    if (need_r) pf.mark(PF_INC0);
+    if (mk) pf.mark(PF_INC0);
   }
   __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
   if (need_r && rmode != 2) {
