@@ -296,19 +296,22 @@ __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, f
 // lexicographic Gauss-Seidel sweeps, in the reference's exact dependency order.
 //
 // One wave marches a strip of 16 rows along j.  Lane = 16*k + c: sweep k (0..3), row
-// i = I0 - k + c, at step tau it updates column j = tau - c - k + 1.  With this skew the four
-// neighbours of cell (i,j) in sweep k were produced exactly one step earlier:
-//   d[i-1][j] (sweep k)   by lane (k, c-1)   -> DPP row_shr:1      (c == 0: carry row in LDS)
-//   d[i][j-1] (sweep k)   by this lane       -> register
-//   d[i+1][j] (sweep k-1) by lane (k-1, c)   -> ds_bpermute        (k == 0: d0 = r*inv from LDS)
-//   d[i][j+1] (sweep k-1) by lane (k-1, c-1) -> DPP of the permuted value (c == 0: carry row)
-// which is what the sequential loops see, so every cell gets the reference's bits.  The last row
-// of each sweep is kept in `carry` for the next strip; the strip of sweep k is shifted up by k
-// rows so that sweep k never overtakes sweep k-1.  r and d live in 24-row LDS rings that all four
-// waves fill/drain with coalesced accesses; out-of-domain neighbours read as 0 (ghost d is 0 on
-// the finest level and multiplies a zero face coefficient on the coarse ones).
+// i = I0 - k + c (the strip of sweep k is shifted up by k rows so that sweep k never overtakes
+// sweep k-1); at step tau the lane updates column j = tau - c - kLag*k + 1.  The four neighbours of
+// cell (i,j) in sweep k:
+//   d[i-1][j] (sweep k)   lane (k, c-1), one step earlier -> DPP row_shr:1   (c == 0: the row above, finished
+//                                                                             by the previous strip, in the ring)
+//   d[i][j-1] (sweep k)   this lane, one step earlier     -> register
+//   d[i+1][j] (sweep k-1) | stored IN PLACE in the d ring by the previous sweep kLag steps earlier (sweep 0: d0 =
+//   d[i][j+1] (sweep k-1) | r*inv from the fill) and overwritten by this very sweep one step later
+// which is what the sequential loops see, so every cell gets the reference's bits.  r and d live in 24-row LDS rings
+// that all four waves fill/drain with coalesced accesses; out-of-domain neighbours read as 0 (ghost d is 0 on the
+// finest level and multiplies a zero face coefficient on the coarse ones).
 // Coefficients: on strips that do not touch the bodies they are synthesised from the level's
 // analytic description (LevelDesc), otherwise loaded per cell.
+// (Round 1 exchanged the sweeps through registers -- lane-16 by two gfx950 row swaps, 8 of its 22 vector
+// instructions per step, one step of lag -- and kept the boundary rows of a strip in separate carry rows; the
+// in-place form below does 14-15 and runs the finest level's march 18 % faster alone, 4 % on the whole step.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 24;
 
@@ -317,18 +320,10 @@ __device__ __forceinline__ float dpp_row_shr1(float old, float src) {
                                                                 0x111, 0xF, 0xF, false));
 }
 
-// value held by lane-16 (rows of 16 lanes): two gfx950 row swaps + one select, no LDS round trip
-__device__ __forceinline__ float lane_minus16(float v, int lane) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);        // a[0] = [r0,r0,r2,r2], a[1] = [r1,r1,r3,r3]
-  auto b = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);  // b[0] = [r0,r0,r1,r1]
-  return __builtin_bit_cast(float, ((lane >> 4) == 3) ? a[0] : b[0]);   //      -> [ *,r0,r1,r2]
-}
-
 // LDS layout used by the smoother (floats, PW = m + kPad):
-//   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][carry 4*PW][kPad][zero row PW][kPad][dummy row PW]
+//   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][zero row PW][kPad][dummy row PW]
 __device__ __host__ __forceinline__ int gs_lds_floats(int m) {
-  return 28 /*kPad*/ + (2 * 24 /*kRing*/ + 4 + 2) * (m + 28) + 4 * 28;
+  return 36 /*kPad*/ + (2 * 24 /*kRing*/ + 2) * (m + 36) + 3 * 36;
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
@@ -353,11 +348,16 @@ __device__ __forceinline__ void coef_analytic(const LevelDesc &D, const DescU &d
 // reads the all-zero row `zrow` and writes to `dummy`.  One unsigned compare per step forces the
 // result of such a lane to 0 (which is also what its neighbours must see: ghost d = 0); its writes
 // are unconditional -- zeros into a pad or the dummy row.
-constexpr int kPad = 28;
+constexpr int kPad = 36;  // >= 34: the last lanes run (and write zeros) up to column m_+35
 
+// The march.  EVERY sweep writes its result in place (as the sequential loops do) and reads d[i+1][j], d[i][j+1] of the
+// previous sweep from LDS; consecutive sweeps follow each other at kLag = 4 steps.  Right after step e of a 4-step
+// chunk has stored its value, the operands of step e of the NEXT chunk are fetched: what they need was stored exactly
+// kLag steps before their use, i.e. by the store just issued (same wave: LDS operations execute in order), and the
+// fetch has four steps to land.
+constexpr int kLag = 4;
 template <bool FAST, bool ZB = true>
-__device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr, float *carry, float *zrow,
-                                         float *dummy, int I0) {
+__device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0) {
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = m + kPad;
   const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
   const int i = I0 - k + c;
@@ -374,36 +374,28 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
   }
   const float cu = uni(D.cu);
   const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
-  const int steps = (m_ + 18 + 3) & ~3;  // multiple of 4 (the extra steps are inactive)
+  const int steps = (m_ + 16 + 3 * kLag + 7) & ~7;  // two chunks per loop iteration (the extra steps are inactive)
   const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
-  // Running LDS pointers: at step tau this lane is at column j = tau + jo (jo = 1-c-k).  Operands of
-  // a 4-step chunk are fetched at the end of the previous chunk, i.e. <= 4 steps early: carry rows
-  // are re-written >= 14 steps after their last read and d0 is overwritten by sweep 3 six columns
-  // behind sweep 0, so nothing fetched early can change in between.  On strips that touch the
-  // bodies the five coefficients come from memory, four columns per 4-byte-aligned 16-byte load, one
-  // chunk ahead.
-  const int jo = 1 - c - k;
+  // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
+  // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
+  // outside the grid read the zero row and write to the dummy row.
+  const int jo = 1 - c - kLag * k;
   const float *p_rv = (row_ok ? rr + slot : zrow) + jo;
-  // lanes c == 0 take d[i-1][j] (sweep k) and d[i][j+1] (sweep k-1) from the carry rows (sweep 3: from
-  // the ring itself, where the previous strip left its final d); sweep 0 takes d0[i][j+1] through
-  // the same register (DPP keeps `old` where no lane feeds it)
   const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
-  const float *p_cW = ((k == 3) ? (rowW_ok ? dr + ((i - 1) % kRing) * PW : zrow) : carry + k * PW) + jo;
-  const float *p_cN = (k == 0) ? ((row_ok ? dr + slot : zrow) + 1 + jo) : (carry + (k - 1) * PW + 1 + jo);
-  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;
-  // one LDS write per step: sweep 3 leaves the final d in the ring, the last row of sweeps 0-2 feeds
-  // the next strip through the carry rows, everything else goes to the dummy row
-  float *w_d = ((k == 3) ? (row_ok ? dr + slot : dummy) : ((c == 15) ? carry + k * PW : dummy)) + jo;
-  float o_rv[4], o_cW[4], o_cN[4], o_dE[4];
+  const float *p_cW = (rowW_ok ? dr + ((i - 1) % kRing) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
+  const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
+  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
+  float *w_d = (row_ok ? dr + slot : dummy) + jo;
+  float aR[4], aW[4], aN[4], aE[4], bR[4], bW[4], bN[4], bE[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    o_rv[e] = p_rv[e];
-    o_cW[e] = p_cW[e];
-    o_cN[e] = p_cN[e];
-    o_dE[e] = p_dE[e];
+    aR[e] = p_rv[e];
+    aW[e] = p_cW[e];
+    aN[e] = p_cN[e];
+    aE[e] = p_dE[e];
   }
-  F4 c_lw, c_le, c_ls, c_iv, x_lw, x_le, x_ls, x_iv;
-  float c_ln4 = 0.f, x_ln4 = 0.f;
+  F4 a_lw, a_le, a_ls, a_iv, b_lw, b_le, b_ls, b_iv;
+  float a_ln4 = 0.f, b_ln4 = 0.f;
   const int cbase = ic * m + jo;  // + tau = flat index of this lane's cell at step tau
 #define GS_CHUNK(TAU, lw_, le_, ls_, iv_, ln4_) \
   {                                             \
@@ -415,13 +407,14 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
     iv_ = load4u(L.inv + kk_);                  \
     ln4_ = L.ly[kk_ + 4];                       \
   }
-  if (!FAST) GS_CHUNK(0, x_lw, x_le, x_ls, x_iv, x_ln4)
+  if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
   float res = 0.f;
   // strips whose 19 rows all lie inside the grid have a stretch of steps in which every lane is at an
   // interior column 2..m_-1: no lane needs the activity mask or a boundary inverse there
   const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
-  // one 4-step chunk; STEADY: no activity mask, interior inverse diagonal
-#define GS_STEPS(STEADY)                                                                                               \
+  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one;
+  // STEADY: no activity mask, interior inverse diagonal
+#define GS3_STEPS(STEADY, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
   _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                      \
     float lw, le, ls, ln, iv;                                                                                          \
     if (FAST) {                                                                                                        \
@@ -430,7 +423,7 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       lw = le = ls = ln = cu;                                                                                          \
       iv = iv0;                                                                                                        \
       if (zb && !(STEADY)) {                                                                                           \
-        const int j = jb + e;                                                                                          \
+        const int j = (T0) + jo + e;                                                                                   \
         iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                                 \
       }                                                                                                                \
     } else {                                                                                                           \
@@ -441,43 +434,30 @@ __device__ __forceinline__ void gs_march(const Lv &L, const float *rr, float *dr
       iv = c_iv.v[e];                                                                                                  \
     }                                                                                                                  \
     const float prev = res;                                                                                            \
-    const float up16 = lane_minus16(prev, lane);  /* (k-1, c): sweep k-1 at (i+1, j) */                                \
-    const float dW = dpp_row_shr1(o_cW[e], prev); /* (k, c-1): sweep k at (i-1, j); c == 0: carry / ring */            \
-    /* (k-1, c-1): sweep k-1 at (i, j+1); c == 0: carry; sweep 0 (DPP row 0 disabled): d0[i][j+1] */                   \
-    const float dN = __builtin_bit_cast(                                                                               \
-        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, o_cN[e]), __builtin_bit_cast(int, up16), 0x111,     \
-                                           0xE, 0xF, false));                                                          \
-    const float dE = (k == 0) ? o_dE[e] : up16;                                                                        \
-    const float v = -(dW * lw + dE * le + prev * ls + dN * ln - o_rv[e]) * iv; /* MG.pde:84-88 */                      \
-    res = ((STEADY) || (unsigned)(jb + e - 1) < m_eff) ? v : 0.f;                                                      \
-    qw_d[e] = res;                                                                                                     \
+    const float dW = dpp_row_shr1(cW[e], prev); /* (k, c-1): sweep k at (i-1, j); c == 0: the row above, in the ring */ \
+    const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv; /* MG.pde:84-88 */                  \
+    res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                               \
+    w_d[(T0) + e] = res;                                                                                               \
+    nR[e] = p_rv[(T0) + 4 + e]; /* operands of the same step of the next chunk: stored kLag steps before their use */  \
+    nW[e] = p_cW[(T0) + 4 + e];                                                                                        \
+    nN[e] = p_cN[(T0) + 4 + e];                                                                                        \
+    nE[e] = p_dE[(T0) + 4 + e];                                                                                        \
   }
-  for (int tau0 = 0; tau0 < steps; tau0 += 4) {
-    if (!FAST) {
-      c_lw = x_lw;
-      c_le = x_le;
-      c_ls = x_ls;
-      c_iv = x_iv;
-      c_ln4 = x_ln4;
-      GS_CHUNK(tau0 + 4, x_lw, x_le, x_ls, x_iv, x_ln4)
-    }
-    float *qw_d = w_d + tau0;
-    const int jb = tau0 + jo;
-    if (FAST && all_rows && tau0 >= 20 && tau0 + 3 <= m_ - 2) {
-      GS_STEPS(true)
-    } else {
-      GS_STEPS(false)
-    }
-    const float *q_rv = p_rv + tau0 + 4, *q_cW = p_cW + tau0 + 4, *q_cN = p_cN + tau0 + 4, *q_dE = p_dE + tau0 + 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // operands of the next chunk (issued after this chunk's LDS writes)
-      o_rv[e] = q_rv[e];
-      o_cW[e] = q_cW[e];
-      o_cN[e] = q_cN[e];
-      o_dE[e] = q_dE[e];
-    }
+#define GS3_CHUNK2(T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, n_ln4)   \
+  {                                                                                                                    \
+    if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
+    if (FAST && all_rows && (T0) >= 16 + 3 * kLag && (T0) + 3 <= m_ - 2) {                                             \
+      GS3_STEPS(true, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                               \
+    } else {                                                                                                           \
+      GS3_STEPS(false, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                              \
+    }                                                                                                                  \
   }
-#undef GS_STEPS
+  for (int tau0 = 0; tau0 < steps; tau0 += 8) {
+    GS3_CHUNK2(tau0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
+    GS3_CHUNK2(tau0 + 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls, a_iv, a_ln4)
+  }
+#undef GS3_CHUNK2
+#undef GS3_STEPS
 #undef GS_CHUNK
 }
 
@@ -721,8 +701,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   const int PW = m + kPad;
   const bool mk = need_r || ((F.desc->dbg_copy >> 20) == n);  // diagnostics: phase marks for the level with n rows
-  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
-        *dummy = zrow + PW + kPad;
+  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
@@ -740,7 +719,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
   const bool grp_on = chunked && (rg < ngrp);
   __syncthreads();
-  // zero everything once: pads, carry rows, the zero row (ring interiors are overwritten by the fills)
+  // zero everything once: pads and the zero row (ring interiors are overwritten by the fills)
   // (the region is shared with the other phases' tiles, so this is redone on every call)
   for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
   lds_barrier();
@@ -801,11 +780,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
-        gs_march<false>(F, rr, dr, carry, zrow, dummy, I0);
+        gs_march3<false>(F, rr, dr, zrow, dummy, I0);
       else if (du.zb)
-        gs_march<true, true>(F, rr, dr, carry, zrow, dummy, I0);
+        gs_march3<true, true>(F, rr, dr, zrow, dummy, I0);
       else
-        gs_march<true, false>(F, rr, dr, carry, zrow, dummy, I0);
+        gs_march3<true, false>(F, rr, dr, zrow, dummy, I0);
       __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();

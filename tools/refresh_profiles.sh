@@ -3,7 +3,7 @@
 #   tools/refresh_profiles.sh <tag>      e.g. r1   -> gpurun_out/profiles_<tag>/
 # bench line, rocprofv3 kernel stats of the same command, steady launch average, HBM traffic (two PMC
 # passes), SQ counters, per-phase time (1024 and 1 envs) and per-phase HBM traffic.
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -25,5 +25,7 @@ python3 tools/pmc_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.json
 python3 tools/phase_traffic.py report $O/pt_f $O/pt_w > $O/${TAG}_phase_traffic.txt
 timeout 200 python tools/phase_profile.py 1024 16 8 > $O/${TAG}_phase_profile_E1024.txt
 timeout 200 python tools/phase_profile.py 1 16 8 > $O/${TAG}_phase_profile_E1.txt
+timeout 300 python tools/phase_times.py 1024 16 > $O/${TAG}_phase_times_E1024.txt 2>&1
+timeout 300 python tools/phase_times.py 1 16 > $O/${TAG}_phase_times_E1.txt 2>&1
 rm -rf $O/stats $O/pmc_f $O/pmc_w $O/pmc_sq $O/pt_f $O/pt_w
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt
