@@ -19,6 +19,46 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
 typedef __attribute__((address_space(3))) int lds_i;
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two consecutive floats, 4-byte aligned
+typedef __attribute__((address_space(3))) f2u lds_f2;
+// One Gauss-Seidel update of the march up to the subtraction of r, as the nine instructions it needs, in the
+// reference's order (MG.pde:84-88): ((dW*lw + dE*le) + dS*ls) + dN*ln - r with dW = lane-1's previous result
+// (DPP row_shr:1; lanes 0,16,32,48 keep `w` = the value from the ring) and dS = this lane's previous result.
+// Written out because (a) left to itself the vectoriser pairs the products into v_pk_mul_f32 and pays three register
+// moves per step, (b) the two products that do not depend on `prev` fill the two wait states the hardware needs
+// between the VALU write of `prev` (the last instruction before this block) and its DPP read.
+// UNI: the four coefficients are wave-uniform (scalar registers).
+#define GS_CORE_ASM                                                \
+  "v_mul_f32 %1, %7, %4\n\t"                                       \
+  "v_mul_f32 %2, %9, %5\n\t"                                       \
+  "v_mov_b32_dpp %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_mul_f32 %0, %6, %0\n\t"                                       \
+  "v_add_f32 %0, %0, %1\n\t"                                       \
+  "v_mul_f32 %1, %8, %3\n\t"                                       \
+  "v_add_f32 %0, %0, %1\n\t"                                       \
+  "v_add_f32 %0, %0, %2\n\t"                                       \
+  "v_sub_f32 %0, %0, %10"
+// UNI: the four coefficients are wave-uniform (scalar registers).  FIN: also the final d = -(...)*inv.
+template <bool UNI, bool FIN>
+__device__ __forceinline__ float gs_core(float prev, float w, float dE, float dN, float r, float lw, float le, float ls,
+                                         float ln, float iv) {
+  float a, b;
+  if (UNI && FIN)
+    asm volatile(GS_CORE_ASM "\n\tv_mul_f32_e64 %0, %11, -%0"
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(iv));
+  else if (UNI)
+    asm volatile(GS_CORE_ASM
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r));
+  else
+    asm volatile(GS_CORE_ASM
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "v"(lw), "v"(le), "v"(ls), "v"(ln), "v"(r));
+  return w;
+}
+#undef GS_CORE_ASM
+__device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)(uintptr_t)(const lds_f *)p; }
 
 // Values that are the same in every lane but reached the wave through vector loads (the level
 // table sits in global memory) occupy a VGPR each and get spilled around the register-hungry
@@ -386,13 +426,17 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
   const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
   float *w_d = (row_ok ? dr + slot : dummy) + jo;
+  // The five streams of a lane as LDS byte addresses that advance by one opaque add per loop iteration (8 steps): every
+  // access below is `base + immediate`, two consecutive steps per instruction (ds_read2_b32 / ds_write2_b32).
+  unsigned q_rv = lds_addr(p_rv), q_cW = lds_addr(p_cW), q_cN = lds_addr(p_cN), q_dE = lds_addr(p_dE), q_wd = lds_addr(w_d);
+#define LD2(q, o) (*(const lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)))
+#define ST2(q, o, v) (*(lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)) = (v))
   float aR[4], aW[4], aN[4], aE[4], bR[4], bW[4], bN[4], bE[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    aR[e] = p_rv[e];
-    aW[e] = p_cW[e];
-    aN[e] = p_cN[e];
-    aE[e] = p_dE[e];
+  for (int h = 0; h < 4; h += 2) {
+    const f2u r2 = LD2(q_rv, h), w2 = LD2(q_cW, h), n2 = LD2(q_cN, h), e2 = LD2(q_dE, h);
+    aR[h] = r2.x, aR[h + 1] = r2.y, aW[h] = w2.x, aW[h + 1] = w2.y;
+    aN[h] = n2.x, aN[h + 1] = n2.y, aE[h] = e2.x, aE[h + 1] = e2.y;
   }
   F4 a_lw, a_le, a_ls, a_iv, b_lw, b_le, b_ls, b_iv;
   float a_ln4 = 0.f, b_ln4 = 0.f;
@@ -409,53 +453,72 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   }
   if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
   float res = 0.f;
-  // strips whose 19 rows all lie inside the grid have a stretch of steps in which every lane is at an
-  // interior column 2..m_-1: no lane needs the activity mask or a boundary inverse there
-  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
-  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one;
-  // STEADY: no activity mask, interior inverse diagonal
-#define GS3_STEPS(STEADY, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
-  _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                      \
-    float lw, le, ls, ln, iv;                                                                                          \
-    if (FAST) {                                                                                                        \
-      /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:         */ \
-      /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                       */ \
-      lw = le = ls = ln = cu;                                                                                          \
-      iv = iv0;                                                                                                        \
-      if (zb && !(STEADY)) {                                                                                           \
-        const int j = (T0) + jo + e;                                                                                   \
-        iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                                 \
+  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
+  // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
+  // fetched (what they need was stored kLag steps before its use, i.e. by the store just issued).  O = offset of the
+  // chunk from the iteration's base addresses; STEADY: no activity mask, interior inverse diagonal
+#define GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
+  _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                                                                   \
+    f2u out;                                                                                                           \
+    _Pragma("unroll") for (int e = h; e < h + 2; ++e) {                                                                \
+      float lw, le, ls, ln, iv;                                                                                        \
+      if (FAST) {                                                                                                      \
+        /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:       */ \
+        /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                     */ \
+        lw = le = ls = ln = cu;                                                                                        \
+        iv = iv0;                                                                                                      \
+        if (zb && !(STEADY)) {                                                                                         \
+          const int j = (T0) + jo + e;                                                                                 \
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                               \
+        }                                                                                                              \
+      } else {                                                                                                         \
+        lw = c_lw.v[e];                                                                                                \
+        le = c_le.v[e];                                                                                                \
+        ls = c_ls.v[e];                                                                                                \
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                    \
+        iv = c_iv.v[e];                                                                                                \
       }                                                                                                                \
-    } else {                                                                                                           \
-      lw = c_lw.v[e];                                                                                                  \
-      le = c_le.v[e];                                                                                                  \
-      ls = c_ls.v[e];                                                                                                  \
-      ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                      \
-      iv = c_iv.v[e];                                                                                                  \
+      /* (k, c-1) holds sweep k at (i-1, j) one step earlier: DPP row_shr:1; c == 0 keeps cW = the row above, in the ring */ \
+      const float t = gs_core<FAST, FAST && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);            \
+      const float v = (FAST && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                             \
+      res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                             \
+      if (e == h) out.x = res; else out.y = res;                                                                       \
     }                                                                                                                  \
-    const float prev = res;                                                                                            \
-    const float dW = dpp_row_shr1(cW[e], prev); /* (k, c-1): sweep k at (i-1, j); c == 0: the row above, in the ring */ \
-    const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv; /* MG.pde:84-88 */                  \
-    res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                               \
-    w_d[(T0) + e] = res;                                                                                               \
-    nR[e] = p_rv[(T0) + 4 + e]; /* operands of the same step of the next chunk: stored kLag steps before their use */  \
-    nW[e] = p_cW[(T0) + 4 + e];                                                                                        \
-    nN[e] = p_cN[(T0) + 4 + e];                                                                                        \
-    nE[e] = p_dE[(T0) + 4 + e];                                                                                        \
+    ST2(q_wd, (O) + h, out);                                                                                           \
+    const f2u r2 = LD2(q_rv, (O) + 4 + h), w2 = LD2(q_cW, (O) + 4 + h);                                                \
+    const f2u n2 = LD2(q_cN, (O) + 4 + h), e2 = LD2(q_dE, (O) + 4 + h);                                                \
+    nR[h] = r2.x, nR[h + 1] = r2.y, nW[h] = w2.x, nW[h + 1] = w2.y;                                                    \
+    nN[h] = n2.x, nN[h + 1] = n2.y, nE[h] = e2.x, nE[h + 1] = e2.y;                                                    \
   }
-#define GS3_CHUNK2(T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, n_ln4)   \
+#define GS3_CHUNK2(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, \
+                   n_ln4)                                                                                              \
   {                                                                                                                    \
     if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
-    if (FAST && all_rows && (T0) >= 16 + 3 * kLag && (T0) + 3 <= m_ - 2) {                                             \
-      GS3_STEPS(true, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                               \
-    } else {                                                                                                           \
-      GS3_STEPS(false, T0, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                              \
-    }                                                                                                                  \
+    GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
   }
-  for (int tau0 = 0; tau0 < steps; tau0 += 8) {
-    GS3_CHUNK2(tau0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
-    GS3_CHUNK2(tau0 + 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls, a_iv, a_ln4)
+#define GS3_ITER(STEADY)                                                                                               \
+  {                                                                                                                    \
+    GS3_CHUNK2(STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, \
+               b_ln4)                                                                                                  \
+    GS3_CHUNK2(STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls,   \
+               a_iv, a_ln4)                                                                                            \
+    /* opaque to the optimiser: the addresses are NOT re-derived from tau0 (one VALU add per access otherwise) */     \
+    asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
+                 "v_add_u32 %4, 32, %4"                                                                                \
+                 : "+v"(q_rv), "+v"(q_cW), "+v"(q_cN), "+v"(q_dE), "+v"(q_wd));                                        \
   }
+  // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
+  // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
+  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
+  const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
+  int tau0 = 0;
+  for (const int lim = steps < 32 ? steps : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
+  if (FAST)
+    for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
+  for (; tau0 < steps; tau0 += 8) GS3_ITER(false)
+#undef GS3_ITER
+#undef LD2
+#undef ST2
 #undef GS3_CHUNK2
 #undef GS3_STEPS
 #undef GS_CHUNK
