@@ -141,7 +141,24 @@ __device__ __forceinline__ float quick_face(float bLm, float bL, float bH, float
 // same fallback flags), so the arithmetic can use packed-f32 instructions (v_pk_add/mul_f32 --
 // per-component IEEE operations, nothing fused, bits unchanged).
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, bool okL, bool okH) {
+typedef unsigned long long lmask;  // one bit per lane, in a scalar register pair
+__device__ __forceinline__ lmask lanes_if(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+// (lane in up ? okL : okH) ? a : b -- the mask logic on the scalar unit, one vector select
+__device__ __forceinline__ float sel_upwind_ok(lmask up, lmask okL, lmask okH, float a, float b) {
+  float r;
+  lmask t1, t2;
+  asm("s_and_b64 %1, %3, %4\n\t"
+      "s_andn2_b64 %2, %5, %3\n\t"
+      "s_or_b64 %1, %1, %2\n\t"
+      "v_cndmask_b32_e64 %0, %7, %6, %1"
+      : "=v"(r), "=&s"(t1), "=&s"(t2)
+      : "s"(up), "s"(okL), "s"(okH), "v"(a), "v"(b)
+      : "scc");
+  return r;
+}
+// okL / okH arrive as LANE MASKS: "upwind ? okL : okH" is then three scalar instructions on the masks instead of a
+// vector select between two booleans (five vector instructions per face and component)
+__device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, lmask okL, lmask okH) {
   const f2 bf = 0.5f * (bL + bH);
   const bool upx = uf.x > 0.f, upy = uf.y > 0.f;
   f2 bc, bd, bu;
@@ -156,8 +173,9 @@ __device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, b
   f2 r;
   const float lx = __builtin_amdgcn_fmed3f(q.x, bc.x, __builtin_amdgcn_fmed3f(bc.x, bd.x, b1.x));
   const float ly = __builtin_amdgcn_fmed3f(q.y, bc.y, __builtin_amdgcn_fmed3f(bc.y, bd.y, b1.y));
-  r.x = (upx ? okL : okH) ? lx : bf.x;
-  r.y = (upy ? okL : okH) ? ly : bf.y;
+  const lmask mx = lanes_if(upx), my = lanes_if(upy);
+  r.x = sel_upwind_ok(mx, okL, okH, lx, bf.x);
+  r.y = sel_upwind_ok(my, okL, okH, ly, bf.y);
   return r;
 }
 
@@ -173,7 +191,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
   const int n = uni(P.n), m = uni(P.m), N = uni(P.N);
   const int R = uni(P.adv_rows), TR = R + 4;
   float *tx = lds + 2, *ty = lds + 2 + TR * m + 4;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave index in a scalar register: row indices and the fallback masks stay on the scalar unit
   const int RW = R >> 2;
   const int j0 = 1 + C * lane;
   const bool lane_on = (j0 <= m - 2);
@@ -238,9 +256,9 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         for (int e = 0; e < C; ++e) {
           const int j = j0 + e;
           if (j > m - 2) break;
-          const bool cok = (j >= 2) && (j <= m - 2);
-          const bool cokN = (j + 1 >= 2) && (j + 1 <= m - 2);
-          const bool cokS = (j - 1 >= 2) && (j - 1 <= m - 2);
+          const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
+          const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
+          const lmask mCS = lanes_if((j - 1 >= 2) && (j - 1 <= m - 2));
           // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
 #define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
           const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
@@ -252,18 +270,18 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           f2 fW;
           if (ii == 0) {
             const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
-            fW = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW && cok, rok && cok);
+            fW = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);
           } else {
             fW = fE2[e];
           }
           const f2 ue = 0.5f * (f2{ce.x, TX(i + 1, j - 1)} + f2{cc.x, ce.x});
-          const f2 fE = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok && cok, rokE && cok);
+          const f2 fE = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok ? mC : 0, rokE ? mC : 0);
           if (e == 0) {
             const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});  // x: y[i][j]+y[i-1][j]; y: y[i][j-1]+y[i][j]
-            fS2 = vs * quick_face2(XY(i, j - 2), cs, cc, cn, vs, rok && cokS, rok && cok);
+            fS2 = vs * quick_face2(XY(i, j - 2), cs, cc, cn, vs, rok ? mCS : 0, rok ? mC : 0);
           }
           const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{TY(i - 1, j + 1), cn.y});
-          const f2 fN = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok && cok, rok && cokN);
+          const f2 fN = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok ? mC : 0, rok ? mCN : 0);
           const f2 adv = ((fW - fE) + (fS2 - fN));
           const f2 dif = ce + cn - 4.f * cc + cw + cs;                           // :198-200
           const f2 o = (adv + nu * dif) * dt + f2{bxv[e], byv[e]};              // :174-175
