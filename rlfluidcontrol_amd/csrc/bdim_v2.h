@@ -1325,6 +1325,13 @@ __device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &C
 // RESID = true : finest level, first iteration: r0 = div(u) - A (pin+s), x_out = (pin+s) + d
 // RESID = false: any level with an existing residual: r0 = F.r, x_out = F.x + d  (F.x is 0 on
 //                coarse levels, MG.pde:56; on the finest level it is the current iterate)
+// LDS: two tiles of TR = R+2 rows (global rows a-1 .. a+R), pitch PT = m+2 floats, a cell of column j at index j+3 so
+// that a thread's four columns 1+4c..4+4c are one aligned 16-byte access: `tr` holds r0, `td` holds d = r0*inv WITH the
+// setBC mirror written into its ghost columns and rows, so that the patches read their 4x6 window of d without any
+// clamping, computed once per cell.  Threads keep their 4-column chunk c4 and walk down rows / row pairs: no division
+// inside the loops.
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+typedef __attribute__((address_space(3))) f4a lds_f4;
 template <bool RESID, bool XZ>
 __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift,
@@ -1337,173 +1344,208 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
     shift = 0.f;
   }
   shift = uni(shift);
-  float *t0 = lds + 8;  // r0 tile: 16 rows, pitch m
   const int tid = threadIdx.x;
   const int m1 = L1.m;
   const DescU du = desc_u(D);
   const bool unif = (du.zb == 0);  // finest level: all coefficients uniform outside the special rows
   // rows per block: 14 on the finest grids; on narrow (coarse) levels enough rows to give every
   // thread a patch (7*k*CPR patches per block), bounded by the 2080-float tile
+  const int PT = m + 2;
   int kblk = 1;
   if (!RESID && !(P.dbg & 1)) {
     kblk = 32 / (CPR > 0 ? CPR : 1);
     if (kblk < 1) kblk = 1;
-    while (kblk > 1 && (14 * kblk + 2) * m > 2080) --kblk;
+    while (kblk > 1 && (14 * kblk + 2) * PT > 2112) --kblk;
   }
   const int R = 14 * kblk, TR = R + 2, NPAIR = 7 * kblk;
+  // 16-byte aligned tiles; index of (tile row t, column j) = t*PT + j + 3
+  const unsigned lbase = (lds_addr(lds) + 15u) & ~15u;
+  const unsigned a_tr = lbase, a_td = lbase + 4u * (unsigned)(TR * PT + 4);
+#define T_R4(t, c) (*(lds_f4 *)(uintptr_t)(a_tr + 4u * (unsigned)((t) * PT + 4 * (c) + 4)))
+#define T_D4(t, c) (*(lds_f4 *)(uintptr_t)(a_td + 4u * (unsigned)((t) * PT + 4 * (c) + 4)))
+#define T_D1(t, j) (*(lds_f *)(uintptr_t)(a_td + 4u * (unsigned)((t) * PT + (j) + 3)))
+  const int ngrp = kThreads / CPR, rg = tid / CPR, c4 = tid - rg * CPR;  // the only divisions of the call
+  const bool on = rg < ngrp;
+  const int j = 1 + 4 * c4;
   for (int a = 1; a <= n_; a += R) {
     const bool sp = (a + R + 1 >= du.sp_i0) && (a - 2 <= du.sp_i1);
     lds_barrier();
-    // ---- step 1: r0 for rows a-1 .. a+R ----
-    for (int q = tid; q < TR * CPR; q += kThreads) {
-      const int t = q / CPR, c4 = q - t * CPR;
-      const int g = a - 1 + t, j = 1 + 4 * c4;
-      if (g < 1 || g > n_) continue;
-      if (!RESID && t == 0) continue;  // row a-1 was overwritten by the previous block: kept in the tile
-      const int k = g * m + j;
-      F4 r0;
-      if (RESID) {
-        const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
-        const float uyn = uy[k + 4];
-        const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
-        const float psl = pin[k - 1], pnr = pin[k + 4];
-        F4 lw, le, ls;
-        float ln4;
-        if (sp) {
-          lw = load4u(L0.lx + k);
-          le = load4u(L0.lx + k + m);
-          ls = load4u(L0.ly + k);
-          ln4 = L0.ly[k + 4];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
-          ln4 = du.cu;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
-          const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
-          const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
-          const float diag = -(lwv + lev + lsv + lnv);
-          const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
-          const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift,
-                      pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
-          const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
-          r0.v[e] = div - ap;
-        }
-      } else {
-        r0 = load4u(r + k);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t0[t * m + j + e] = r0.v[e];
-    }
-    lds_barrier();
-    // ---- step 2: one 2x4 patch per thread ----
-    for (int q = tid; q < NPAIR * CPR; q += kThreads) {
-      const int pr = q / CPR, c4 = q - pr * CPR;
-      const int g = a + 2 * pr, j = 1 + 4 * c4;
-      if (g > n_) continue;
-      // d = r0*inv on rows g-1..g+2, cols j-1..j+4 with the setBC mirror (clamp into the interior)
-      float dd[4][6];
-#pragma unroll
-      for (int a4 = 0; a4 < 4; ++a4) {
-        int gg = g - 1 + a4;
-        gg = gg < 1 ? 1 : (gg > n_ ? n_ : gg);
-        const float *row = t0 + (gg - (a - 1)) * m;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          int jj = j - 1 + b;
-          jj = jj < 1 ? 1 : (jj > m_ ? m_ : jj);
-          float iv;
+    // ---- step 1: r0 and d = r0*inv for rows a-1 .. a+R ----
+    if (on)
+      for (int t = rg; t < TR; t += ngrp) {
+        const int g = a - 1 + t;
+        if (g < 1 || g > n_) continue;
+        if (!RESID && t == 0) continue;  // row a-1 was overwritten by the previous block: kept in the tiles
+        const int k = g * m + j;
+        F4 r0;
+        if (RESID) {
+          const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
+          const float uyn = uy[k + 4];
+          const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
+          const float psl = pin[k - 1], pnr = pin[k + 4];
+          F4 lw, le, ls;
+          float ln4;
           if (sp) {
-            iv = L0.inv[gg * m + jj];
-          } else if (unif) {
-            iv = du.iv0;
+            lw = load4u(L0.lx + k);
+            le = load4u(L0.lx + k + m);
+            ls = load4u(L0.ly + k);
+            ln4 = L0.ly[k + 4];
           } else {
-            iv = D.invtab[3 * ((gg == 1) ? 1 : ((gg == n_) ? 2 : 0)) + ((jj == 1) ? 1 : ((jj == m_) ? 2 : 0))];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+            ln4 = du.cu;
           }
-          dd[a4][b] = row[jj] * iv;  // MG.pde:80
-        }
-      }
-      float rn[2][4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int gg = g + h, k = gg * m + j;
-        F4 lw, le, ls;
-        float ln4;
-        if (sp) {
-          lw = load4u(L0.lx + k);
-          le = load4u(L0.lx + k + m);
-          ls = load4u(L0.ly + k);
-          ln4 = L0.ly[k + 4];
-        } else if (unif) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
-          ln4 = du.cu;
-        } else {
-          float a0, a1, a2, a3, a4v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            coef_analytic(D, du, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
-            lw.v[e] = a0;
-            le.v[e] = a1;
-            ls.v[e] = a2;
-            if (e == 3) ln4 = a3;
+            const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
+            const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
+            const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+            const float diag = -(lwv + lev + lsv + lnv);
+            const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
+            const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift,
+                        pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
+            const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
+            r0.v[e] = div - ap;
           }
-        }
-        F4 pc;  // x before the increment: the iterate on the finest level, exactly zero on coarse ones (MG.pde:56)
-        if (!XZ) {
-          pc = load4u(pin + k);
         } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pc.v[e] = 0.f;
+          r0 = load4u(r + k);
         }
-        const float *r0row = t0 + (gg - (a - 1)) * m + j;
-        F4 xo, ro;
+        F4 iv;
+        if (sp) {
+          iv = load4u(L0.inv + k);
+        } else if (unif) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) iv.v[e] = du.iv0;
+        } else {
+          const int rc = 3 * ((g == 1) ? 1 : ((g == n_) ? 2 : 0));
+          const float i0 = D.invtab[rc];
+          iv.v[0] = (c4 == 0) ? D.invtab[rc + 1] : i0;
+          iv.v[1] = i0;
+          iv.v[2] = i0;
+          iv.v[3] = (c4 == CPR - 1) ? D.invtab[rc + 2] : i0;
+        }
+        f4a r4, d4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
-          const float diag = -(lwv + lev + lsv + lnv);
-          const float d = dd[1 + h][1 + e];
-          const float ad = d * diag + dd[h][1 + e] * lwv + dd[2 + h][1 + e] * lev + dd[1 + h][e] * lsv +
-                           dd[1 + h][2 + e] * lnv;  // PoissonMatrix.pde:57-61
-          rn[h][e] = r0row[e] - ad;                  // MG.pde:96
-          ro.v[e] = rn[h][e];
-          xo.v[e] = (pc.v[e] + shift) + d;           // MG.pde:95
+          r4[e] = r0.v[e];
+          d4[e] = r0.v[e] * iv.v[e];  // MG.pde:80
         }
-        store4u(pout + k, xo);
-        store4u(r + k, ro);
-        // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
-        if (c4 == 0) pout[k - 1] = ((XZ ? 0.f : pin[k - 1]) + shift) + dd[1 + h][1];
-        if (c4 == CPR - 1) pout[k + 4] = ((XZ ? 0.f : pin[k + 4]) + shift) + dd[1 + h][4];
-        const bool top = (gg == 1), bot = (gg == n_);
-        if (top || bot) {
-          const int kg = (top ? 0 : (n - 1)) * m + j;
-          F4 pg;
-          if (!XZ) {
-            pg = load4u(pin + kg);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pg.v[e] = 0.f;
+        T_R4(t, c4) = r4;
+        T_D4(t, c4) = d4;
+        // d.setBC(): ghosts mirror the adjacent interior cell (Field.pde:211-224)
+        if (c4 == 0) T_D1(t, 0) = d4[0];
+        if (c4 == CPR - 1) T_D1(t, m_ + 1) = d4[3];
+        if (g == 1 || g == n_) {
+          const int tg = (g == 1) ? t - 1 : t + 1;
+          if (tg >= 0 && tg < TR) {
+            T_D4(tg, c4) = d4;
+            if (c4 == 0) T_D1(tg, 0) = d4[0];
+            if (c4 == CPR - 1) T_D1(tg, m_ + 1) = d4[3];
           }
-          F4 xg;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + dd[1 + h][1 + e];
-          store4u(pout + kg, xg);
-          if (c4 == 0) pout[kg - 1] = ((XZ ? 0.f : pin[kg - 1]) + shift) + dd[1 + h][1];
-          if (c4 == CPR - 1) pout[kg + 4] = ((XZ ? 0.f : pin[kg + 4]) + shift) + dd[1 + h][4];
         }
       }
-      // restrict (MG.pde:124-137): sum of the 2x2 children, reference order
-      const int ci = (g - 1) / 2 + 1, cj = (j - 1) / 2 + 1;
-      L1.r[ci * m1 + cj] = rn[0][0] + rn[0][1] + rn[1][0] + rn[1][1];
-      L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
-    }
-    if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row 14) must keep its ORIGINAL r
+    lds_barrier();
+    // ---- step 2: one 2x4 patch per thread ----
+    if (on)
+      for (int pr = rg; pr < NPAIR; pr += ngrp) {
+        const int g = a + 2 * pr;
+        if (g > n_) continue;
+        const int tq = g - (a - 1);  // tile row of g
+        // d on rows g-1..g+2, cols j-1..j+4
+        float dd[4][6];
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+          const f4a v = T_D4(tq - 1 + a4, c4);
+          dd[a4][0] = T_D1(tq - 1 + a4, j - 1);
+          dd[a4][1] = v[0], dd[a4][2] = v[1], dd[a4][3] = v[2], dd[a4][4] = v[3];
+          dd[a4][5] = T_D1(tq - 1 + a4, j + 4);
+        }
+        float rn[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gg = g + h, k = gg * m + j;
+          F4 lw, le, ls;
+          float ln4;
+          if (sp) {
+            lw = load4u(L0.lx + k);
+            le = load4u(L0.lx + k + m);
+            ls = load4u(L0.ly + k);
+            ln4 = L0.ly[k + 4];
+          } else if (unif) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+            ln4 = du.cu;
+          } else {
+            float a0, a1, a2, a3, a4v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              coef_analytic(D, du, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
+              lw.v[e] = a0;
+              le.v[e] = a1;
+              ls.v[e] = a2;
+              if (e == 3) ln4 = a3;
+            }
+          }
+          F4 pc;  // x before the increment: the iterate on the finest level, exactly zero on coarse ones (MG.pde:56)
+          if (!XZ) {
+            pc = load4u(pin + k);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pc.v[e] = 0.f;
+          }
+          const f4a r0row = T_R4(tq + h, c4);
+          F4 xo, ro;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+            const float diag = -(lwv + lev + lsv + lnv);
+            const float d = dd[1 + h][1 + e];
+            const float ad = d * diag + dd[h][1 + e] * lwv + dd[2 + h][1 + e] * lev + dd[1 + h][e] * lsv +
+                             dd[1 + h][2 + e] * lnv;  // PoissonMatrix.pde:57-61
+            rn[h][e] = r0row[e] - ad;                  // MG.pde:96
+            ro.v[e] = rn[h][e];
+            xo.v[e] = (pc.v[e] + shift) + d;           // MG.pde:95
+          }
+          store4u(pout + k, xo);
+          store4u(r + k, ro);
+          // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+          if (c4 == 0) pout[k - 1] = ((XZ ? 0.f : pin[k - 1]) + shift) + dd[1 + h][1];
+          if (c4 == CPR - 1) pout[k + 4] = ((XZ ? 0.f : pin[k + 4]) + shift) + dd[1 + h][4];
+          const bool top = (gg == 1), bot = (gg == n_);
+          if (top || bot) {
+            const int kg = (top ? 0 : (n - 1)) * m + j;
+            F4 pg;
+            if (!XZ) {
+              pg = load4u(pin + kg);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pg.v[e] = 0.f;
+            }
+            F4 xg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + dd[1 + h][1 + e];
+            store4u(pout + kg, xg);
+            if (c4 == 0) pout[kg - 1] = ((XZ ? 0.f : pin[kg - 1]) + shift) + dd[1 + h][1];
+            if (c4 == CPR - 1) pout[kg + 4] = ((XZ ? 0.f : pin[kg + 4]) + shift) + dd[1 + h][4];
+          }
+        }
+        // restrict (MG.pde:124-137): sum of the 2x2 children, reference order
+        const int ci = (g - 1) / 2 + 1, cj = (j - 1) / 2 + 1;
+        L1.r[ci * m1 + cj] = rn[0][0] + rn[0][1] + rn[1][0] + rn[1][1];
+        L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
+      }
+    if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row R) must keep its ORIGINAL r (and its d)
       lds_barrier();
-      for (int q = tid; q < m; q += kThreads) t0[q] = t0[R * m + q];
+      for (int q = tid; q <= PT; q += kThreads) {  // indices 3 .. PT of the row are in use
+        lds_f *tr1 = (lds_f *)(uintptr_t)a_tr, *td1 = (lds_f *)(uintptr_t)a_td;
+        tr1[q] = tr1[R * PT + q];
+        td1[q] = td1[R * PT + q];
+      }
     }
   }
+#undef T_R4
+#undef T_D4
+#undef T_D1
   __syncthreads();
 }
 
