@@ -23,20 +23,22 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two conse
 typedef __attribute__((address_space(3))) f2u lds_f2;
 // One Gauss-Seidel update of the march up to the subtraction of r, as the nine instructions it needs, in the
 // reference's order (MG.pde:84-88): ((dW*lw + dE*le) + dS*ls) + dN*ln - r with dW = lane-1's previous result
-// (DPP row_shr:1; lanes 0,16,32,48 keep `w` = the value from the ring) and dS = this lane's previous result.
-// Written out because (a) left to itself the vectoriser pairs the products into v_pk_mul_f32 and pays three register
-// moves per step, (b) the two products that do not depend on `prev` fill the two wait states the hardware needs
+// (DPP row_shr:1 folded INTO the multiply; lanes 0,16,32,48 have no DPP source and keep `w*lw`, the value from the
+// ring times the coefficient, formed one instruction earlier) and dS = this lane's previous result.
+// The march is bound by the LATENCY of this dependent chain (a dependent VALU instruction issues ~9.5 cycles after
+// its producer, an independent one after ~5: tools/valu_lat.hip), so what counts is its depth: mul_dpp, three adds,
+// sub, mul = 6.  The two leading products do not depend on `prev` and fill the two wait states the hardware needs
 // between the VALU write of `prev` (the last instruction before this block) and its DPP read.
 // UNI: the four coefficients are wave-uniform (scalar registers).
-#define GS_CORE_ASM                                                \
-  "v_mul_f32 %1, %7, %4\n\t"                                       \
-  "v_mul_f32 %2, %9, %5\n\t"                                       \
-  "v_mov_b32_dpp %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"  \
-  "v_mul_f32 %0, %6, %0\n\t"                                       \
-  "v_add_f32 %0, %0, %1\n\t"                                       \
-  "v_mul_f32 %1, %8, %3\n\t"                                       \
-  "v_add_f32 %0, %0, %1\n\t"                                       \
-  "v_add_f32 %0, %0, %2\n\t"                                       \
+#define GS_CORE_ASM                                                          \
+  "v_mul_f32 %0, %6, %0\n\t"                                                 \
+  "v_mul_f32 %1, %7, %4\n\t"                                                 \
+  "v_mul_f32_dpp %0, %3, %11 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"       \
+  "v_mul_f32 %2, %8, %3\n\t"                                                 \
+  "v_add_f32 %0, %0, %1\n\t"                                                 \
+  "v_mul_f32 %1, %9, %5\n\t"                                                 \
+  "v_add_f32 %0, %0, %2\n\t"                                                 \
+  "v_add_f32 %0, %0, %1\n\t"                                                 \
   "v_sub_f32 %0, %0, %10"
 // UNI: the four coefficients are wave-uniform (scalar registers).  FIN: also the final d = -(...)*inv.
 template <bool UNI, bool FIN>
@@ -44,17 +46,17 @@ __device__ __forceinline__ float gs_core(float prev, float w, float dE, float dN
                                          float ln, float iv) {
   float a, b;
   if (UNI && FIN)
-    asm volatile(GS_CORE_ASM "\n\tv_mul_f32_e64 %0, %11, -%0"
+    asm volatile(GS_CORE_ASM "\n\tv_mul_f32_e64 %0, %12, -%0"
                  : "+v"(w), "=&v"(a), "=&v"(b)
-                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(iv));
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw), "v"(iv));
   else if (UNI)
     asm volatile(GS_CORE_ASM
                  : "+v"(w), "=&v"(a), "=&v"(b)
-                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r));
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw));
   else
     asm volatile(GS_CORE_ASM
                  : "+v"(w), "=&v"(a), "=&v"(b)
-                 : "v"(prev), "v"(dE), "v"(dN), "v"(lw), "v"(le), "v"(ls), "v"(ln), "v"(r));
+                 : "v"(prev), "v"(dE), "v"(dN), "v"(lw), "v"(le), "v"(ls), "v"(ln), "v"(r), "v"(lw));
   return w;
 }
 #undef GS_CORE_ASM
