@@ -1,4 +1,4 @@
-// Cycles per step of the ordered Gauss-Seidel march (gs_march of bdim_v2.h) in isolation:
+// Cycles per step of the ordered Gauss-Seidel march (gs_march3 of bdim_v2.h) in isolation:
 // one wave per workgroup marches NS strips of a 256x128 level out of LDS; WG workgroups per launch
 // (256 = one per CU, 1024 = four per CU).  Prints ns and core cycles (2.4 GHz nominal) per step.
 #include "../rlfluidcontrol_amd/csrc/bdim_v2.h"
@@ -7,18 +7,17 @@
 #include <vector>
 using namespace afc;
 #ifndef MARCH_CALL
-#define MARCH_CALL                                                  \
-  if (D.zero_bnd)                                                   \
-    gs_march<true, true>(L, rr, dr, carry, zrow, dummy, I0);        \
-  else                                                              \
-    gs_march<true, false>(L, rr, dr, carry, zrow, dummy, I0)
+#define MARCH_CALL                                           \
+  if (D.zero_bnd)                                            \
+    gs_march3<true, true>(L, rr, dr, zrow, dummy, I0);       \
+  else                                                       \
+    gs_march3<true, false>(L, rr, dr, zrow, dummy, I0)
 #endif
 __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstrips, float *out, long long *ticks,
                                              const float *coef, int generic) {
   extern __shared__ float lds[];
   const int PW = m + kPad;
-  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *carry = dr + kRing * PW + kPad, *zrow = carry + 4 * PW + kPad,
-        *dummy = zrow + PW + kPad;
+  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
   for (int q = threadIdx.x; q < gs_lds_floats(m); q += blockDim.x) lds[q] = 0.f;
   __syncthreads();
   for (int q = threadIdx.x; q < kRing * PW; q += blockDim.x) {
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstri
     for (int s = 0; s < nstrips; ++s) {
       const int I0 = 17 + 16 * (s % 13);  // interior strips
       if (generic)
-        gs_march<false>(L, rr, dr, carry, zrow, dummy, I0);
+        gs_march3<false>(L, rr, dr, zrow, dummy, I0);
       else
         MARCH_CALL;
     }
@@ -73,7 +72,7 @@ int main(int argc, char **argv) {
   long long *ticks;
   hipMalloc(&out, 1024 * 4);
   hipMalloc(&ticks, 1024 * 8);
-  const int steps_per_strip = (m - 2 + 18 + 3) & ~3;
+  const int steps_per_strip = (m - 2 + 16 + 3 * kLag + 7) & ~7;
   const int generic = argc > 2 ? atoi(argv[2]) : 0;
   float *coef;
   {
