@@ -144,6 +144,10 @@ __device__ __forceinline__ float quick_face(float bLm, float bL, float bH, float
 // per-component IEEE operations, nothing fused, bits unchanged).
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long lmask;  // one bit per lane, in a scalar register pair
+__device__ __forceinline__ float lane_prev_keep(float own, float v) {  // lane-1's v (whole wave); lane 0 keeps `own`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, v), 0x138,
+                                                                0xF, 0xF, false));
+}
 __device__ __forceinline__ lmask lanes_if(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 // (lane in up ? okL : okH) ? a : b -- the mask logic on the scalar unit, one vector select
 __device__ __forceinline__ float sel_upwind_ok(lmask up, lmask okL, lmask okH, float a, float b) {
@@ -227,7 +231,6 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         const bool rok = (i >= 2) && (i <= n - 2);       // row part of the fallback test for cells of row i
         const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
         const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
-        f2 fS2 = {0.f, 0.f};
         // the lane's C cells are contiguous: one (4-byte aligned) C-float load/store per array
         const bool full = (j0 + C - 1 <= m - 2);
         float bxv[C], byv[C], oxv[C], oyv[C];
@@ -254,44 +257,60 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
             byv[e] = in ? by[i * m + j0 + e] : 0.f;
           }
         }
+        // pass 1: the east and north faces of the lane's cells; pass 2 combines.  The south face of the lane's FIRST cell
+        // is the north face of lane-1's LAST cell -- same cells, same fallback flags, evaluated once (DPP wave_shr:1);
+        // lane 0 sits at the wall, where the face is in the fallback zone: its value is the plain average.
+        f2 fEn[C], fNn[C], ccv[C], difv[C];
+        f2 fSw = {0.f, 0.f};  // lane 0: vs * 0.5*(cs + cc)
 #pragma unroll
         for (int e = 0; e < C; ++e) {
           const int j = j0 + e;
           if (j > m - 2) break;
           const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
           const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
-          const lmask mCS = lanes_if((j - 1 >= 2) && (j - 1 <= m - 2));
           // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
 #define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
           const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
-          if (xdbg & 16) {
-            oxv[e] = cc.x + bxv[e];
-            oyv[e] = cc.y + byv[e];
-            continue;
-          }
-          f2 fW;
+          ccv[e] = cc;
+          if (xdbg & 16) continue;
           if (ii == 0) {
             const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
-            fW = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);
-          } else {
-            fW = fE2[e];
+            fE2[e] = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);  // = this row's west face
           }
           const f2 ue = 0.5f * (f2{ce.x, TX(i + 1, j - 1)} + f2{cc.x, ce.x});
-          const f2 fE = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok ? mC : 0, rokE ? mC : 0);
+          fEn[e] = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok ? mC : 0, rokE ? mC : 0);
           if (e == 0) {
             const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});  // x: y[i][j]+y[i-1][j]; y: y[i][j-1]+y[i][j]
-            fS2 = vs * quick_face2(XY(i, j - 2), cs, cc, cn, vs, rok ? mCS : 0, rok ? mC : 0);
+            fSw = vs * (0.5f * (cs + cc));
           }
           const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{TY(i - 1, j + 1), cn.y});
-          const f2 fN = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok ? mC : 0, rok ? mCN : 0);
-          const f2 adv = ((fW - fE) + (fS2 - fN));
-          const f2 dif = ce + cn - 4.f * cc + cw + cs;                           // :198-200
-          const f2 o = (adv + nu * dif) * dt + f2{bxv[e], byv[e]};              // :174-175
+          fNn[e] = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok ? mC : 0, rok ? mCN : 0);
+          difv[e] = ce + cn - 4.f * cc + cw + cs;                           // :198-200
+#undef XY
+        }
+        {  // the last cell the lane owns in this row (a partial last lane owns fewer than C)
+          f2 last = fNn[0];
+#pragma unroll
+          for (int e = 1; e < C; ++e)
+            if (j0 + e <= m - 2) last = fNn[e];
+          fSw.x = lane_prev_keep(fSw.x, last.x);
+          fSw.y = lane_prev_keep(fSw.y, last.y);
+        }
+#pragma unroll
+        for (int e = 0; e < C; ++e) {
+          const int j = j0 + e;
+          if (j > m - 2) break;
+          if (xdbg & 16) {
+            oxv[e] = ccv[e].x + bxv[e];
+            oyv[e] = ccv[e].y + byv[e];
+            continue;
+          }
+          const f2 fW = fE2[e], fS = (e == 0) ? fSw : fNn[e > 0 ? e - 1 : 0];
+          const f2 adv = ((fW - fEn[e]) + (fS - fNn[e]));
+          const f2 o = (adv + nu * difv[e]) * dt + f2{bxv[e], byv[e]};              // :174-175
           oxv[e] = o.x;
           oyv[e] = o.y;
-          fE2[e] = fE;
-          fS2 = fN;
-#undef XY
+          fE2[e] = fEn[e];
         }
         if (xdbg & 32) {
           if (oxv[0] == 12345.678f) dx[i * m + j0] = oyv[0];  // keeps the values live, never taken
