@@ -28,4 +28,5 @@ timeout 200 python tools/phase_profile.py 1 16 8 > $O/${TAG}_phase_profile_E1.tx
 timeout 300 python tools/phase_times.py 1024 16 > $O/${TAG}_phase_times_E1024.txt 2>&1
 timeout 300 python tools/phase_times.py 1 16 > $O/${TAG}_phase_times_E1.txt 2>&1
 rm -rf $O/stats $O/pmc_f $O/pmc_w $O/pmc_sq $O/pt_f $O/pt_w
+bash tools/phase_insts.sh $O/${TAG}_phase_insts.txt > /dev/null 2>&1
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt
