@@ -61,9 +61,11 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
   float pshift = G(P.sc)[e].p_shift;
+  afc::gate_init(P);
+  __syncthreads();
   if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
   step_dispatch<CPL>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
-  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P);
+  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P, true);
   if (threadIdx.x == 0) {
     EnvScalars &s = G(P.sc)[e];
     s.p_shift = pshift;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     s.window_done = 0;
     s_stop = 0;
   }
+  afc::gate_init(P);
   __syncthreads();
   if (CPL != 0) afc::gate_acquire(P);
   const float xi1_m = afc::uni(s.xi1_m), xi2_m = afc::uni(s.xi2_m);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     __syncthreads();
     if (s_stop) break;
   }
-  if (CPL != 0) afc::gate_release(P);
+  if (CPL != 0) afc::gate_release(P, true);
   if (threadIdx.x == 0) {
     s.p_shift = pshift;
     G(P.sc)[e] = s;
@@ -619,7 +622,23 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_alloc(env, &env->d_P, (size_t)1);
   if (!rc) rc = dev_alloc(env, &P.gate, (size_t)256);
   if (!rc && hipMemset(G(P.gate), 0, 256 * sizeof(int)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
-  P.gate_limit = (cfg->reserved[0] >> 16) & 15;  // experiment switch (dbg bits 16-19)
+  P.gate_limit = (cfg->reserved[0] >> 16) & 15;  // dbg bits 16-19: 1..14 per-CU tokens (experiment), 15 = populations
+  P.gate_n[0] = P.gate_n[1] = 0;
+  for (int b = 0; b < (int)E; ++b) P.gate_n[(b >> 3) & 1]++;
+  if (P.gate_limit == 15) {  // taking turns needs every workgroup of a launch resident at once (a waiting workgroup
+                             // would otherwise hold the slot of the one it waits for) and two non-empty populations
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    bool ok = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess);
+    if (ok) cus = prop.multiProcessorCount;
+    switch (env->cpl) {
+#define OCC(c) case c: ok = ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_agent_step<c>, kThreads, env->lds_bytes) == hipSuccess); break
+      OCC(1); OCC(2); OCC(3); OCC(4);
+#undef OCC
+      default: ok = false;
+    }
+    if (!ok || (long long)per_cu * cus < (long long)E || P.gate_n[0] == 0 || P.gate_n[1] == 0) P.gate_limit = 0;
+  }
   if (!rc) rc = dev_alloc(env, &env->d_stamps, (size_t)32);
   if (!rc && hipMemset(env->d_stamps, 0, 32 * sizeof(long long)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (rc) {
@@ -858,6 +877,7 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
     dforce = env->d_f2;
   }
   if (int rcp = sync_params(env)) return rcp;
+  if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
   switch (env->cpl) {
 #define LAUNCH(c) case c: hipLaunchKernelGGL(k_sim_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break
     LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
@@ -897,6 +917,7 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   const int warm = (int)(env->cfg.init_time / per);
   const int max_steps = (warm > 0 ? warm : 0) + 2 * env->cfg.substeps + 8;
   if (int rcp = sync_params(env)) return rcp;
+  if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
   switch (env->cpl) {
 #define LAUNCH(c) case c: hipLaunchKernelGGL(k_agent_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break
     LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
@@ -1185,7 +1206,9 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   HIP_TRY(hipMemcpy(G(P.fx), b, bytes, hipMemcpyHostToDevice));
   int *dit = reinterpret_cast<int *>(env->d_i32);
   float *dl = env->d_f1;
-  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P, dit, dl);
+  StepParams Pq = P;
+  Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
+  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));

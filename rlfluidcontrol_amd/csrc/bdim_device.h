@@ -93,7 +93,8 @@ struct StepParams {
   AFC_AS1 EnvScalars *sc;
   AFC_AS1 long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
   AFC_AS1 int *gate;          // [256] streaming-phase tokens per group of workgroups that share a CU (experiment)
-  int gate_limit;             // 0 = off; else at most this many workgroups of a group are in a streaming phase
+  int gate_limit;             // 0 = off; 1..14 = per-CU token count (experiment); 15 = two populations of CUs take turns
+  int gate_n[2];              // workgroups per population (gate_limit 15)
   // episode constants
   float act_scale, init_time, end_time, reward_penalty;
   int substeps, carry_quirk, exact_sums;
@@ -143,25 +144,57 @@ struct Prof {
 enum { PF_ADVDIF = 0, PF_FORCING, PF_SETBC, PF_RESID, PF_DOWN0, PF_COARSE_DOWN, PF_COARSE_GS, PF_COARSE_UP, PF_UP0,
        PF_GS0, PF_INC0, PF_RR, PF_PROJECT, PF_HEUN, PF_COUNT };
 
-// ---- streaming-phase gate (experiment): workgroups b, b+256, b+512, ... tend to share a CU; at most gate_limit of them
-// may be in the HBM-heavy part of the step (projection tail .. solve head) at a time, so that the latency-bound
-// multigrid part of their CU mates runs beside it instead of beside more multigrid.  Speed only, never correctness.
+// ---- streaming-phase gate: workgroups b, b+256, b+512, ... share a CU (tools/hwid_test.hip).
+// gate_limit 1..14 (experiment): at most gate_limit of the workgroups of a CU may be in the HBM-heavy part of the step
+// (projection tail .. solve head) at a time.
+// gate_limit 15 = two POPULATIONS of CUs taking turns: population 0 (CUs with bit 3 of the block index clear) streams
+// while population 1 is in its multigrid part, and vice versa -- the streaming half of the chip then has the HBM to
+// itself and no marching wave has a streaming neighbour on its CU.  cnt[p] counts the streaming parts population p has
+// completed (all of its workgroups together); the k-th streaming part of a workgroup of population 0 starts when
+// population 1 has completed k of them, the k-th of population 1 when population 0 has completed k+1.  A workgroup that
+// leaves the kernel adds 2^20 (more than any threshold of a launch, and 512 of them still fit an int), so nobody ever
+// waits for a workgroup that is gone; the host clears the
+// counters before every launch and switches the mode on only when every workgroup of the launch is resident at once.
+// Speed only, never correctness.
+__device__ __forceinline__ int &gate_round() {
+  __shared__ int k;
+  return k;
+}
+__device__ inline void gate_init(const StepParams &P) {
+  if (P.gate_limit == 15 && threadIdx.x == 0) gate_round() = 0;
+}
 __device__ inline void gate_acquire(const StepParams &P) {
   if (P.gate_limit <= 0) return;
   if (threadIdx.x == 0) {
-    int *g = G(P.gate) + (blockIdx.x & 255);
-    while (true) {
-      const int v = __hip_atomic_fetch_add(g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v < P.gate_limit) break;
-      __hip_atomic_fetch_add(g, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_s_sleep(64);
+    if (P.gate_limit == 15) {
+      const int pop = (blockIdx.x >> 3) & 1, k = gate_round();
+      gate_round() = k + 1;
+      const int need = pop ? P.gate_n[0] * (k + 1) : P.gate_n[1] * k;
+      int *other = G(P.gate) + 32 * (1 - pop);
+      // bounded: a turn that does not come within ~50 ms is taken anyway (speed only, never a hang)
+      for (int spin = 0; spin < (1 << 15) && __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin)
+        __builtin_amdgcn_s_sleep(32);
+    } else {
+      int *g = G(P.gate) + (blockIdx.x & 255);
+      while (true) {
+        const int v = __hip_atomic_fetch_add(g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < P.gate_limit) break;
+        __hip_atomic_fetch_add(g, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(64);
+      }
     }
   }
   __syncthreads();
 }
-__device__ inline void gate_release(const StepParams &P) {
+__device__ inline void gate_release(const StepParams &P, bool leaving = false) {
   if (P.gate_limit <= 0) return;
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(G(P.gate) + (blockIdx.x & 255), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    if (P.gate_limit == 15)
+      __hip_atomic_fetch_add(G(P.gate) + 32 * ((blockIdx.x >> 3) & 1), leaving ? (1 << 20) : 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    else
+      __hip_atomic_fetch_add(G(P.gate) + (blockIdx.x & 255), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---- workgroup reductions (fixed tree order => deterministic) ----
