@@ -237,6 +237,31 @@ def _rank_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dbg,what", [(4, "all-waves smoother"), (15 << 16, "CU populations taking turns"),
+                                      (2, "r written back on every V-cycle")])
+def test_experiment_paths_are_bit_identical_to_the_default(envmod, dbg, what):
+    """the alternative execution paths kept behind `dbg` switches change WHEN and BY WHOM the work is done,
+    never a bit of the result: 40 envs with different actions, agent steps through the warm-up, parity mode"""
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, (40, 2)).astype(np.float32)
+    outs = []
+    for d in (0, dbg):
+        g = envmod.AFCEnv(num_envs=40, resolution=16, reynolds=100, exact_sums=1, init_time=0.05, dbg=d)
+        rec = []
+        for _ in range(3):
+            obs, rew, done, ns = g.agent_step(a)
+            rec.append((obs.copy(), rew.copy(), ns.copy()))
+        u, v, p = g.get_state(7)
+        outs.append((rec, u.copy(), v.copy(), p.copy()))
+        g.close()
+    (r0, u0, v0, p0), (r1, u1, v1, p1) = outs
+    for (o0, w0, n0), (o1, w1, n1) in zip(r0, r1):
+        assert np.array_equal(o0.view(np.uint32), o1.view(np.uint32)), what
+        assert np.array_equal(w0.view(np.uint32), w1.view(np.uint32)) and np.array_equal(n0, n1), what
+    for x, y in ((u0, u1), (v0, v1), (p0, p1)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), what
+
+
 def test_two_gpu_gather_every_rank_sees_the_same_batch():
     """one RCCL all-gather of (obs, reward, done) per agent step; needs 2 GPUs (skipped otherwise)"""
     import torch
