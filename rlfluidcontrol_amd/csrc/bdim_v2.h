@@ -453,7 +453,9 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   }
   const float cu = uni(D.cu);
   const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
-  const int steps = (m_ + 16 + 3 * kLag + 7) & ~7;  // two chunks per loop iteration (the extra steps are inactive)
+  // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
+  // iteration and possibly one more at the end
+  const int steps = (m_ + 15 + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
   const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
   // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
   // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
@@ -551,10 +553,12 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
   const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
   int tau0 = 0;
-  for (const int lim = steps < 32 ? steps : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
+  for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
   if (FAST)
     for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
-  for (; tau0 < steps; tau0 += 8) GS3_ITER(false)
+  for (; tau0 < steps8; tau0 += 8) GS3_ITER(false)
+  if (tau0 < steps)
+    GS3_CHUNK2(false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
 #undef GS3_ITER
 #undef LD2
 #undef ST2

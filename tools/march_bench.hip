@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
   long long *ticks;
   hipMalloc(&out, 1024 * 4);
   hipMalloc(&ticks, 1024 * 8);
-  const int steps_per_strip = (m - 2 + 16 + 3 * kLag + 7) & ~7;
+  const int steps_per_strip = (m - 2 + 15 + 3 * kLag + 3) & ~3;
   const int generic = argc > 2 ? atoi(argv[2]) : 0;
   float *coef;
   {
