@@ -1,0 +1,53 @@
+"""The bench line the driver parses: the committed round-2 line has every field of the contract, its numbers are
+consistent with each other, and bench.py's argument parser keeps the contract's flags (CPU only, nothing is launched)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
+        return json.loads(f.read().strip().split("\n")[-1])
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_committed_bench_line_is_self_consistent():
+    d = _line()
+    r = d["roofline"]
+    envs, sub = d["config"]["envs_per_gpu"], d["config"]["sim_steps_per_agent_step"]
+    # value = env-sim-steps per second of the whole job
+    assert abs(d["value"] - envs * sub * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    # achieved = 176 B per interior cell and sim-step over the launch duration measured with HIP events
+    alg = 176.0 * 256 * 128 * sub * envs
+    assert abs(r["achieved"] - alg / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 1.0 < r["traffic"] / alg < 1.5  # measured HBM bytes per launch against the algorithmic figure
+    # the launch average and the wall-clock step agree (one launch per step, nothing else in the timed region)
+    assert abs(r["avg_launch_ms"] - d["ms_per_step"]) / d["ms_per_step"] < 0.02
+
+
+def test_bench_cli_keeps_the_contract_flags():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
