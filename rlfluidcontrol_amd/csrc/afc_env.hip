@@ -516,7 +516,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.adv_rows = (sf.m <= 130) ? 16 : 8;
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
-    const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 2;  // advdif_v2
+    const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 8;  // advdif_v2 (16-byte aligned tiles)
     const size_t rings = (size_t)afc::gs_lds_floats(sf.m) + 64;  // mg_up_smooth (single-wave march, kept for A/B)
     size_t fl = tile > rings ? tile : rings;
     // multi-wave smoother: both rings of every level live in the same region; with four workgroups per CU a

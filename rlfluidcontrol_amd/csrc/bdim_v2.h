@@ -196,21 +196,49 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
                                  float *__restrict__ dy, float *lds) {
   const int n = uni(P.n), m = uni(P.m), N = uni(P.N);
   const int R = uni(P.adv_rows), TR = R + 4;
-  float *tx = lds + 2, *ty = lds + 2 + TR * m + 4;
+  // diagnostics: 16 = no stencil arithmetic, 32 = no global stores, 64 = no tile loads, 512 = tiles staged through registers
+  const int xdbg = uni(P.dbg);
+  // tiles on 16-byte boundaries (the LDS-DMA copies below write 16 bytes per lane); TR*m + 4 floats apart, a multiple
+  // of 16 bytes whenever TR*m is a multiple of 4
+  float *tx = lds + 4 + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2), *ty = tx + TR * m + 4;
+  const bool dma_ok = (((TR * m) & 3) == 0) && !(xdbg & 512);
   const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave index in a scalar register: row indices and the fallback masks stay on the scalar unit
   const int RW = R >> 2;
   const int j0 = 1 + C * lane;
   const bool lane_on = (j0 <= m - 2);
   const float nu = uni(P.nu), dt = uni(P.dt);
   const bool same = (bx == sx) && (by == sy);
-  const int xdbg = uni(P.dbg);  // diagnostics: 16 = no stencil arithmetic, 32 = no global stores, 64 = no tile loads
   for (int a = 1; a <= n - 2; a += R) {
     // ---- stage rows a-2 .. a+R+1 of src into LDS (flat, coalesced float2) ----
     const int t0 = (a - 2) * m;                    // flat index of tile row 0
     const int lo = t0 < 0 ? 0 : t0;
     const int hi = ((a + R + 2) * m < N) ? (a + R + 2) * m : N;
     lds_barrier();  // previous block's readers are done
-    if (!(xdbg & 64))
+    if (dma_ok && t0 >= 0 && (a + R + 2) * m <= N && !(xdbg & 64)) {
+      // whole blocks (all but the first and the last): the tile is a flat copy of TR*m contiguous floats per field,
+      // moved by the LDS-DMA path (global_load_lds_dwordx4: 1 KB per wave instruction straight into LDS -- no
+      // registers, no ds_write, no address arithmetic; source 4-byte aligned, destination = wave-uniform base +
+      // 16*lane, tools/glds_test.hip)
+      const int nfl = TR * m;
+      for (int p0 = wave * 256; p0 < nfl; p0 += 4 * 256) {
+        const int q = p0 + 4 * lane;
+        if (q < nfl) {
+          __builtin_amdgcn_global_load_lds(sx + t0 + q, (__attribute__((address_space(3))) void *)(tx + p0), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(sy + t0 + q, (__attribute__((address_space(3))) void *)(ty + p0), 16, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(xdbg & (64 | 512))) {
+      // first / last block (the tile hangs over the array): the same path 4 bytes per lane, 256 B per instruction
+      const int nfl = hi - lo, o0 = lo - t0;
+      for (int p0 = wave * 64; p0 < nfl; p0 += 4 * 64) {
+        if (p0 + lane < nfl) {
+          __builtin_amdgcn_global_load_lds(sx + lo + p0 + lane, (__attribute__((address_space(3))) void *)(tx + o0 + p0), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(sy + lo + p0 + lane, (__attribute__((address_space(3))) void *)(ty + o0 + p0), 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(xdbg & 64))
     for (int q = lo + 2 * threadIdx.x; q < hi; q += 2 * kThreads) {
       const float2 vx = *reinterpret_cast<const float2 *>(sx + q);
       const float2 vy = *reinterpret_cast<const float2 *>(sy + q);
