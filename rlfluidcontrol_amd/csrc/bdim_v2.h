@@ -418,14 +418,10 @@ __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, f
 // analytic description (LevelDesc), otherwise loaded per cell.
 // (Round 1 exchanged the sweeps through registers -- lane-16 by two gfx950 row swaps, 8 of its 22 vector
 // instructions per step, one step of lag -- and kept the boundary rows of a strip in separate carry rows; the
-// in-place form below does 14-15 and runs the finest level's march 18 % faster alone, 4 % on the whole step.)
+// in-place form below issues 10 vector + 2.5 LDS instructions per step and runs the finest level's march at 0.55 of
+// that time.  DESIGN.md section 3 has the stages and what bounds it now.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 24;
-
-__device__ __forceinline__ float dpp_row_shr1(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                                0x111, 0xF, 0xF, false));
-}
 
 // LDS layout used by the smoother (floats, PW = m + kPad):
 //   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][zero row PW][kPad][dummy row PW]
@@ -458,10 +454,10 @@ __device__ __forceinline__ void coef_analytic(const LevelDesc &D, const DescU &d
 constexpr int kPad = 36;  // >= 34: the last lanes run (and write zeros) up to column m_+35
 
 // The march.  EVERY sweep writes its result in place (as the sequential loops do) and reads d[i+1][j], d[i][j+1] of the
-// previous sweep from LDS; consecutive sweeps follow each other at kLag = 4 steps.  Right after step e of a 4-step
-// chunk has stored its value, the operands of step e of the NEXT chunk are fetched: what they need was stored exactly
-// kLag steps before their use, i.e. by the store just issued (same wave: LDS operations execute in order), and the
-// fetch has four steps to land.
+// previous sweep from LDS; consecutive sweeps follow each other at kLag = 4 steps.  Right after steps e, e+1 of a
+// 4-step chunk have stored their values (one ds_write2_b32), the operands of the same two steps of the NEXT chunk are
+// fetched (ds_read2_b32): what they need was stored exactly kLag steps before their use, i.e. by the store just issued
+// (same wave: LDS operations execute in order), and the fetch has two to three steps to land.
 constexpr int kLag = 4;
 template <bool FAST, bool ZB = true>
 __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0) {
