@@ -41,16 +41,20 @@ using afc::StepParams;
 // CPL = columns per lane of the optimised kernels (grid height m-2 <= 64*CPL); CPL = 0 selects the
 // straightforward reference kernels.  One instantiation per CPL keeps each kernel's register
 // budget at 4 workgroups (16 waves) per CU.
-template <int CPL>
+// DIAG selects the instantiation of the optimised phases with the diagnostics compiled in (bdim_v2.h); the shipped
+// kernels are <CPL, false>.
+template <int CPL, bool DIAG>
 __device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
                                               double *sm, afc::ShBcast *sh, float *lds) {
   if constexpr (CPL == 0)
     afc::sim_step(P, e, a, b, sm, sh);
+  else if constexpr (DIAG)
+    afc::diag::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
   else
-    afc::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
+    afc::prod::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
 }
 
-template <int CPL>
+template <int CPL, bool DIAG>
 __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams *__restrict__ Pp,
                                                                const float *__restrict__ xi_m,
                                                                float *__restrict__ force) {
@@ -61,11 +65,11 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
   const size_t e = blockIdx.x;
   const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
   float pshift = G(P.sc)[e].p_shift;
-  afc::gate_init(P);
+  if (DIAG) afc::gate_init(P);
   __syncthreads();
-  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
-  step_dispatch<CPL>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
-  if (CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P, true);
+  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
+  step_dispatch<CPL, DIAG>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
+  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P, true);
   if (threadIdx.x == 0) {
     EnvScalars &s = G(P.sc)[e];
     s.p_shift = pshift;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams 
 }
 
 // The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
-template <int CPL>
+template <int CPL, bool DIAG>
 __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParams *__restrict__ Pp,
                                                                  const float *__restrict__ action,
                                                                  float *__restrict__ obs, float *__restrict__ reward,
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   __shared__ afc::ShBcast sh;
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
-  if (P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
+  if (DIAG && P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
     const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
   }
@@ -119,17 +123,17 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     s.window_done = 0;
     s_stop = 0;
   }
-  afc::gate_init(P);
+  if (DIAG) afc::gate_init(P);
   __syncthreads();
-  if (CPL != 0) afc::gate_acquire(P);
-  const float xi1_m = afc::uni(s.xi1_m), xi2_m = afc::uni(s.xi2_m);
+  if (DIAG && CPL != 0) afc::gate_acquire(P);
+  const float xi1_m = afc::prod::uni(s.xi1_m), xi2_m = afc::prod::uni(s.xi2_m);
   float pshift = s.p_shift;
   int steps = 0;
   long long dbg_t0 = 0;
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
-    if ((P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
-    step_dispatch<CPL>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
+    if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
+    step_dispatch<CPL, DIAG>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
     ++steps;
     if (threadIdx.x == 0) {
       s.t += P.dt / P.resolution;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     __syncthreads();
     if (s_stop) break;
   }
-  if (CPL != 0) afc::gate_release(P, true);
+  if (DIAG && CPL != 0) afc::gate_release(P, true);
   if (threadIdx.x == 0) {
     s.p_shift = pshift;
     G(P.sc)[e] = s;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
     done[e] = (!(s.t < P.end_time)) ? 1 : 0;
     if (nsteps) nsteps[e] = steps;
-    if (P.dbg & 8) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
+    if (DIAG && (P.dbg & 8)) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
       obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
       obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
     }
@@ -267,6 +271,7 @@ __global__ void k_cfl(StepParams P, float *__restrict__ out) {
 }
 
 // unit-level operators on env 0 (same device functions as the step)
+template <bool DIAG>
 __global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
   extern __shared__ float lds_dyn[];
   if (P.impl == 0) {
@@ -279,15 +284,24 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
   }
   __syncthreads();
   const int m_ = P.m - 2;
-  if (m_ <= 64) afc::advdif_v2<1>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
-  else if (m_ <= 128) afc::advdif_v2<2>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
-  else if (m_ <= 192) afc::advdif_v2<3>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
-  else afc::advdif_v2<4>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);
+#define ADV(c)                                                                                          \
+  do {                                                                                                  \
+    if constexpr (DIAG)                                                                                 \
+      afc::diag::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);      \
+    else                                                                                                \
+      afc::prod::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);      \
+  } while (0)
+  if (m_ <= 64) ADV(1);
+  else if (m_ <= 128) ADV(2);
+  else if (m_ <= 192) ADV(3);
+  else ADV(4);
+#undef ADV
 }
 __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   __shared__ double sm[afc::kThreads];
   afc::phase_setbc_u(P, 0, sm);
 }
+template <bool DIAG>
 __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iters, float *linf) {
   __shared__ double sm[afc::kThreads];
   // b is staged in fx; x in p.  r = b - A x  (MG.pde:51)
@@ -306,17 +320,24 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iter
   }
   __syncthreads();
   float l;
-  afc::Prof pf;
-  pf.start(P);
   extern __shared__ float lds_dyn[];
   int it;
   if (P.impl == 0) {
+    afc::Prof pf;
+    pf.start(P);
     it = afc::mg_solve(P, 0, sm, &l, pf);
   } else {
     afc::Lv L0v = afc::make_level(P, 0, 0);
     L0v.d = G(P.u0y);
     float xs;
-    it = afc::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    if constexpr (DIAG) {
+      afc::diag::ProfT pf;
+      pf.start(P);
+      it = afc::diag::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    } else {
+      afc::prod::ProfT pf;
+      it = afc::prod::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    }
   }
   if (threadIdx.x == 0) {
     *iters = it;
@@ -412,6 +433,12 @@ int sync_params(afc_env *env) {
   HIP_TRY(hipStreamSynchronize(env->stream));
   env->p_dirty = false;
   return AFC_OK;
+}
+
+// the instantiation with the diagnostics compiled in runs only when one of them is switched on
+bool need_diag(const afc_env *env) {
+  const StepParams &P = env->P;
+  return P.dbg != 0 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
 }
 
 int launch_check(const char *what) {
@@ -517,7 +544,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
     const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 8;  // advdif_v2 (16-byte aligned tiles)
-    const size_t rings = (size_t)afc::gs_lds_floats(sf.m) + 64;  // mg_up_smooth (single-wave march, kept for A/B)
+    const size_t rings = (size_t)afc::prod::gs_lds_floats(sf.m) + 64;  // mg_up_smooth (single-wave march, kept for A/B)
     size_t fl = tile > rings ? tile : rings;
     // multi-wave smoother: both rings of every level live in the same region; with four workgroups per CU a
     // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)
@@ -559,7 +586,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
         const int budget = (int)(env->lds_bytes / sizeof(float));
         int H = L.n - 2 + 3;  // never more lanes than rows (+ the three shifted ones)
         if (H > 62) H = 62;  // lane 0 re-plays the row above the strip, lane H+1 holds the coefficients of the row below
-        while (H > 4 && afc::mw_lds_floats(L.m, H) > budget) --H;
+        while (H > 4 && afc::prod::mw_lds_floats(L.m, H) > budget) --H;
         D.mw_H = H;
         D.dbg_copy = cfg->reserved[0];
       }
@@ -632,7 +659,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     bool ok = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess);
     if (ok) cus = prop.multiProcessorCount;
     switch (env->cpl) {
-#define OCC(c) case c: ok = ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_agent_step<c>, kThreads, env->lds_bytes) == hipSuccess); break
+#define OCC(c) case c: ok = ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_agent_step<c, true>, kThreads, env->lds_bytes) == hipSuccess); break
       OCC(1); OCC(2); OCC(3); OCC(4);
 #undef OCC
       default: ok = false;
@@ -878,9 +905,11 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
   }
   if (int rcp = sync_params(env)) return rcp;
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
+  const bool dg = need_diag(env);
   switch (env->cpl) {
-#define LAUNCH(c) case c: hipLaunchKernelGGL(k_sim_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break
-    LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#define LAUNCH(c) case c: if (dg) hipLaunchKernelGGL((k_sim_step<c, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); else hipLaunchKernelGGL((k_sim_step<c, false>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break
+    case 0: hipLaunchKernelGGL((k_sim_step<0, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break;
+    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
 #undef LAUNCH
   }
   int rc = launch_check("k_sim_step");
@@ -918,9 +947,11 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   const int max_steps = (warm > 0 ? warm : 0) + 2 * env->cfg.substeps + 8;
   if (int rcp = sync_params(env)) return rcp;
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
+  const bool dg = need_diag(env);
   switch (env->cpl) {
-#define LAUNCH(c) case c: hipLaunchKernelGGL(k_agent_step<c>, dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break
-    LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#define LAUNCH(c) case c: if (dg) hipLaunchKernelGGL((k_agent_step<c, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); else hipLaunchKernelGGL((k_agent_step<c, false>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break
+    case 0: hipLaunchKernelGGL((k_agent_step<0, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
+    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
 #undef LAUNCH
   }
   int rc = launch_check("k_agent_step");
@@ -1168,7 +1199,10 @@ int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const fl
   HIP_TRY(hipMemcpy(G(P.uy), fy, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0x), u0x, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0y), u0y, bytes, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_op_advdif, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
+  if (need_diag(env))
+    hipLaunchKernelGGL(k_op_advdif<true>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
+  else
+    hipLaunchKernelGGL(k_op_advdif<false>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
   int rc = launch_check("k_op_advdif");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
@@ -1208,7 +1242,10 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   float *dl = env->d_f1;
   StepParams Pq = P;
   Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
-  hipLaunchKernelGGL(k_op_mg, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
+  if (need_diag(env))
+    hipLaunchKernelGGL(k_op_mg<true>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
+  else
+    hipLaunchKernelGGL(k_op_mg<false>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));

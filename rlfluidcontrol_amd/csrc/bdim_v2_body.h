@@ -1,0 +1,1906 @@
+// bdim_v2.h -- optimised phases of the per-env BDIM step (same arithmetic, same bits as
+// bdim_device.h's reference kernels; selected with StepParams.impl == 2).
+//
+// Velocity buffers rotate instead of being copied (BDIM.pde:82,91 copy u0/us):
+//   A = (ux,uy)   state at the start of the step (= u0 of both half-steps)
+//   B = (usx,usy) predictor result  (= `us` of the corrector)
+//   C = (fx,fy)   corrector result; Heun average (A = (C+B)/2) lands back in A.
+// (included twice by bdim_v2.h: AFC_NS = prod with AFC_DIAG 0, AFC_NS = diag with AFC_DIAG 1)
+
+namespace afc {
+namespace AFC_NS {
+
+#if AFC_DIAG
+typedef Prof ProfT;
+#define AFC_DBG_OF(P) ((P).dbg)
+#else
+struct ProfT {  // the shipped build: no stamps, no stop codes
+  static constexpr int stop = 0;
+  __device__ __forceinline__ void start(const StepParams &) {}
+  __device__ __forceinline__ void mark(int) {}
+};
+#define AFC_DBG_OF(P) 0
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store of the wave (s_waitcnt vmcnt(0)), which puts a store round trip on the critical path
+// of each tile of a streaming loop; inside those loops nothing read from global memory was written
+// by this workgroup in the same phase, so only the LDS hand-over needs ordering.  Phase boundaries
+// keep __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
+typedef __attribute__((address_space(3))) int lds_i;
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two consecutive floats, 4-byte aligned
+typedef __attribute__((address_space(3))) f2u lds_f2;
+// One Gauss-Seidel update of the march up to the subtraction of r, as the nine instructions it needs, in the
+// reference's order (MG.pde:84-88): ((dW*lw + dE*le) + dS*ls) + dN*ln - r with dW = lane-1's previous result
+// (DPP row_shr:1 folded INTO the multiply; lanes 0,16,32,48 have no DPP source and keep `w*lw`, the value from the
+// ring times the coefficient, formed one instruction earlier) and dS = this lane's previous result.
+// The march is bound by the LATENCY of this dependent chain (a dependent VALU instruction issues ~9.5 cycles after
+// its producer, an independent one after ~5: tools/valu_lat.hip), so what counts is its depth: mul_dpp, three adds,
+// sub, mul = 6.  The two leading products do not depend on `prev` and fill the two wait states the hardware needs
+// between the VALU write of `prev` (the last instruction before this block) and its DPP read.
+// UNI: the four coefficients are wave-uniform (scalar registers).
+#define GS_CORE_ASM                                                          \
+  "v_mul_f32 %0, %6, %0\n\t"                                                 \
+  "v_mul_f32 %1, %7, %4\n\t"                                                 \
+  "v_mul_f32_dpp %0, %3, %11 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"       \
+  "v_mul_f32 %2, %8, %3\n\t"                                                 \
+  "v_add_f32 %0, %0, %1\n\t"                                                 \
+  "v_mul_f32 %1, %9, %5\n\t"                                                 \
+  "v_add_f32 %0, %0, %2\n\t"                                                 \
+  "v_add_f32 %0, %0, %1\n\t"                                                 \
+  "v_sub_f32 %0, %0, %10"
+// UNI: the four coefficients are wave-uniform (scalar registers).  FIN: also the final d = -(...)*inv.
+template <bool UNI, bool FIN>
+__device__ __forceinline__ float gs_core(float prev, float w, float dE, float dN, float r, float lw, float le, float ls,
+                                         float ln, float iv) {
+  float a, b;
+  if (UNI && FIN)
+    asm volatile(GS_CORE_ASM "\n\tv_mul_f32_e64 %0, %12, -%0"
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw), "v"(iv));
+  else if (UNI)
+    asm volatile(GS_CORE_ASM
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw));
+  else
+    asm volatile(GS_CORE_ASM
+                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "v"(prev), "v"(dE), "v"(dN), "v"(lw), "v"(le), "v"(ls), "v"(ln), "v"(r), "v"(lw));
+  return w;
+}
+#undef GS_CORE_ASM
+__device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)(uintptr_t)(const lds_f *)p; }
+
+// Values that are the same in every lane but reached the wave through vector loads (the level
+// table sits in global memory) occupy a VGPR each and get spilled around the register-hungry
+// loops; readfirstlane moves them to SGPRs.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T *uni(T *p) {  // p points to GLOBAL memory (all our field / table pointers do)
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  // rebuilt as an address-space-1 pointer so that accesses stay global_* (SGPR base) instead of flat_*
+  return (T *)reinterpret_cast<AFC_AS1 T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Lv uni(const Lv &L) {
+  Lv U;
+  U.n = uni(L.n);
+  U.m = uni(L.m);
+  U.lx = uni(L.lx);
+  U.ly = uni(L.ly);
+  U.inv = uni(L.inv);
+  U.r = uni(L.r);
+  U.x = uni(L.x);
+  U.d = uni(L.d);
+  {  // the descriptor may sit in a by-value copy of the parameters (kernel arguments / private memory in
+     // the operator kernels): keep that pointer generic
+    const unsigned long long a = reinterpret_cast<unsigned long long>(L.desc);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    U.desc = reinterpret_cast<const LevelDesc *>(((unsigned long long)hi << 32) | lo);
+  }
+  return U;
+}
+struct DescU {  // the scalar fields of a LevelDesc, in SGPRs
+  float cu, iv0;
+  int zb, sp_i0, sp_i1;
+};
+__device__ __forceinline__ DescU desc_u(const LevelDesc &D) {
+  DescU u;
+  u.cu = uni(D.cu);
+  u.iv0 = uni(D.invtab[0]);
+  u.zb = uni(D.zero_bnd);
+  u.sp_i0 = uni(D.sp_i0);
+  u.sp_i1 = uni(D.sp_i1);
+  return u;
+}
+
+struct F4 {
+  float v[4];
+};
+__device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byte load (global_load_dwordx4)
+  F4 r;
+  __builtin_memcpy(&r, p, 16);
+  return r;
+}
+__device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
+
+// One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
+// and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
+// flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
+// The reference evaluates every interior face twice (as the E face of L and the W face of H, or
+// N/S) with identical operands -- addition is commutative -- so one evaluation serves both
+// cells bit for bit; for uf == 0 the two evaluations may pick different upwind cells but the
+// flux uf*value is +-0 either way.
+__device__ __forceinline__ float quick_face(float bLm, float bL, float bH, float bHp, float uf, bool okL,
+                                            bool okH) {
+  const float bf = 0.5f * (bL + bH);
+  const bool up = uf > 0.f;
+  const float bc = up ? bL : bH, bd = up ? bH : bL, bu = up ? bLm : bHp;
+  const bool ok = up ? okL : okH;
+  const float q = bf - (1.f / 6.f) * (bd - 2 * bc + bu);
+  const float b1 = bu + 10.f * (bc - bu);
+  const float lim = __builtin_amdgcn_fmed3f(q, bc, __builtin_amdgcn_fmed3f(bc, bd, b1));  // :218,221-223
+  return ok ? lim : bf;
+}
+
+// The same for the x- and the y-component at once: both faces have the same geometry (same cells,
+// same fallback flags), so the arithmetic can use packed-f32 instructions (v_pk_add/mul_f32 --
+// per-component IEEE operations, nothing fused, bits unchanged).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long lmask;  // one bit per lane, in a scalar register pair
+__device__ __forceinline__ float lane_prev_keep(float own, float v) {  // lane-1's v (whole wave); lane 0 keeps `own`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, v), 0x138,
+                                                                0xF, 0xF, false));
+}
+__device__ __forceinline__ lmask lanes_if(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+// (lane in up ? okL : okH) ? a : b -- the mask logic on the scalar unit, one vector select
+__device__ __forceinline__ float sel_upwind_ok(lmask up, lmask okL, lmask okH, float a, float b) {
+  float r;
+  lmask t1, t2;
+  asm("s_and_b64 %1, %3, %4\n\t"
+      "s_andn2_b64 %2, %5, %3\n\t"
+      "s_or_b64 %1, %1, %2\n\t"
+      "v_cndmask_b32_e64 %0, %7, %6, %1"
+      : "=v"(r), "=&s"(t1), "=&s"(t2)
+      : "s"(up), "s"(okL), "s"(okH), "v"(a), "v"(b)
+      : "scc");
+  return r;
+}
+// okL / okH arrive as LANE MASKS: "upwind ? okL : okH" is then three scalar instructions on the masks instead of a
+// vector select between two booleans (five vector instructions per face and component)
+__device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, lmask okL, lmask okH) {
+  const f2 bf = 0.5f * (bL + bH);
+  const bool upx = uf.x > 0.f, upy = uf.y > 0.f;
+  f2 bc, bd, bu;
+  bc.x = upx ? bL.x : bH.x;
+  bd.x = upx ? bH.x : bL.x;
+  bu.x = upx ? bLm.x : bHp.x;
+  bc.y = upy ? bL.y : bH.y;
+  bd.y = upy ? bH.y : bL.y;
+  bu.y = upy ? bLm.y : bHp.y;
+  const f2 q = bf - (1.f / 6.f) * (bd - 2.f * bc + bu);
+  const f2 b1 = bu + 10.f * (bc - bu);
+  f2 r;
+  const float lx = __builtin_amdgcn_fmed3f(q.x, bc.x, __builtin_amdgcn_fmed3f(bc.x, bd.x, b1.x));
+  const float ly = __builtin_amdgcn_fmed3f(q.y, bc.y, __builtin_amdgcn_fmed3f(bc.y, bd.y, b1.y));
+  const lmask mx = lanes_if(upx), my = lanes_if(upy);
+  r.x = sel_upwind_ok(mx, okL, okH, lx, bf.x);
+  r.y = sel_upwind_ok(my, okL, okH, ly, bf.y);
+  return r;
+}
+
+// F = (advection + nu*diffusion)(src)*dt + base on interior cells (VectorField.AdvDif,
+// VectorField.pde:170-179), streamed through an LDS tile of R+4 rows.  Wave w owns R/4
+// consecutive rows of the block and carries the east-face flux down the rows; lane l owns C
+// adjacent columns and carries the north-face flux across them.  Non-interior cells of dst are
+// NOT written (setbc_vel defines them).
+template <int C>
+__device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
+                                 const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
+                                 float *__restrict__ dy, float *lds) {
+  const int n = uni(P.n), m = uni(P.m), N = uni(P.N);
+  const int R = uni(P.adv_rows), TR = R + 4;
+  // diagnostics: 16 = no stencil arithmetic, 32 = no global stores, 64 = no tile loads, 512 = tiles staged through registers
+  const int xdbg = uni(AFC_DBG_OF(P));
+  // tiles on 16-byte boundaries (the LDS-DMA copies below write 16 bytes per lane); TR*m + 4 floats apart, a multiple
+  // of 16 bytes whenever TR*m is a multiple of 4
+  float *tx = lds + 4 + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2), *ty = tx + TR * m + 4;
+  const bool dma_ok = (((TR * m) & 3) == 0) && !(xdbg & 512);
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave index in a scalar register: row indices and the fallback masks stay on the scalar unit
+  const int RW = R >> 2;
+  const int j0 = 1 + C * lane;
+  const bool lane_on = (j0 <= m - 2);
+  const float nu = uni(P.nu), dt = uni(P.dt);
+  const bool same = (bx == sx) && (by == sy);
+  for (int a = 1; a <= n - 2; a += R) {
+    // ---- stage rows a-2 .. a+R+1 of src into LDS (flat, coalesced float2) ----
+    const int t0 = (a - 2) * m;                    // flat index of tile row 0
+    const int lo = t0 < 0 ? 0 : t0;
+    const int hi = ((a + R + 2) * m < N) ? (a + R + 2) * m : N;
+    lds_barrier();  // previous block's readers are done
+    if (dma_ok && t0 >= 0 && (a + R + 2) * m <= N && !(xdbg & 64)) {
+      // whole blocks (all but the first and the last): the tile is a flat copy of TR*m contiguous floats per field,
+      // moved by the LDS-DMA path (global_load_lds_dwordx4: 1 KB per wave instruction straight into LDS -- no
+      // registers, no ds_write, no address arithmetic; source 4-byte aligned, destination = wave-uniform base +
+      // 16*lane, tools/glds_test.hip)
+      const int nfl = TR * m;
+      for (int p0 = wave * 256; p0 < nfl; p0 += 4 * 256) {
+        const int q = p0 + 4 * lane;
+        if (q < nfl) {
+          __builtin_amdgcn_global_load_lds(sx + t0 + q, (__attribute__((address_space(3))) void *)(tx + p0), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(sy + t0 + q, (__attribute__((address_space(3))) void *)(ty + p0), 16, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(xdbg & (64 | 512))) {
+      // first / last block (the tile hangs over the array): the same path 4 bytes per lane, 256 B per instruction
+      const int nfl = hi - lo, o0 = lo - t0;
+      for (int p0 = wave * 64; p0 < nfl; p0 += 4 * 64) {
+        if (p0 + lane < nfl) {
+          __builtin_amdgcn_global_load_lds(sx + lo + p0 + lane, (__attribute__((address_space(3))) void *)(tx + o0 + p0), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(sy + lo + p0 + lane, (__attribute__((address_space(3))) void *)(ty + o0 + p0), 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(xdbg & 64))
+    for (int q = lo + 2 * threadIdx.x; q < hi; q += 2 * kThreads) {
+      const float2 vx = *reinterpret_cast<const float2 *>(sx + q);
+      const float2 vy = *reinterpret_cast<const float2 *>(sy + q);
+      tx[q - t0] = vx.x;
+      tx[q - t0 + 1] = vx.y;
+      ty[q - t0] = vy.x;
+      ty[q - t0 + 1] = vy.y;
+    }
+    lds_barrier();
+#define TX(gi, gj) tx[((gi) - (a - 2)) * m + (gj)]
+#define TY(gi, gj) ty[((gi) - (a - 2)) * m + (gj)]
+    if (lane_on) {
+      const int i_beg = a + wave * RW;
+      f2 fE2[C];
+      for (int ii = 0; ii < RW; ++ii) {
+        const int i = i_beg + ii;
+        if (i > n - 2) break;
+        const bool rok = (i >= 2) && (i <= n - 2);       // row part of the fallback test for cells of row i
+        const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
+        const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
+        // the lane's C cells are contiguous: one (4-byte aligned) C-float load/store per array
+        const bool full = (j0 + C - 1 <= m - 2);
+        float bxv[C], byv[C], oxv[C], oyv[C];
+        if (same) {  // predictor: the base field is the advected field, already in the tile
+#pragma unroll
+          for (int e = 0; e < C; ++e) {
+            const int jj = (j0 + e <= m - 2) ? j0 + e : m - 2;
+            bxv[e] = TX(i, jj);
+            byv[e] = TY(i, jj);
+          }
+        } else if (full) {
+          // the lane offset is made opaque per row: otherwise `base + lane offset` is hoisted out of the
+          // row loop as two 64-bit lane addresses that do not fit the register file and come back from
+          // scratch, one dependent round trip each, in front of every base-field load
+          int off = i * m + j0;
+          asm volatile("" : "+v"(off));
+          __builtin_memcpy(bxv, bx + off, sizeof(float) * C);
+          __builtin_memcpy(byv, by + off, sizeof(float) * C);
+        } else {
+#pragma unroll
+          for (int e = 0; e < C; ++e) {
+            const bool in = (j0 + e <= m - 2);
+            bxv[e] = in ? bx[i * m + j0 + e] : 0.f;
+            byv[e] = in ? by[i * m + j0 + e] : 0.f;
+          }
+        }
+        // pass 1: the east and north faces of the lane's cells; pass 2 combines.  The south face of the lane's FIRST cell
+        // is the north face of lane-1's LAST cell -- same cells, same fallback flags, evaluated once (DPP wave_shr:1);
+        // lane 0 sits at the wall, where the face is in the fallback zone: its value is the plain average.
+        f2 fEn[C], fNn[C], ccv[C], difv[C];
+        f2 fSw = {0.f, 0.f};  // lane 0: vs * 0.5*(cs + cc)
+#pragma unroll
+        for (int e = 0; e < C; ++e) {
+          const int j = j0 + e;
+          if (j > m - 2) break;
+          const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
+          const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
+          // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
+#define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
+          const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
+          ccv[e] = cc;
+          if (xdbg & 16) continue;
+          if (ii == 0) {
+            const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
+            fE2[e] = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);  // = this row's west face
+          }
+          const f2 ue = 0.5f * (f2{ce.x, TX(i + 1, j - 1)} + f2{cc.x, ce.x});
+          fEn[e] = ue * quick_face2(cw, cc, ce, XY(i + 2, j), ue, rok ? mC : 0, rokE ? mC : 0);
+          if (e == 0) {
+            const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});  // x: y[i][j]+y[i-1][j]; y: y[i][j-1]+y[i][j]
+            fSw = vs * (0.5f * (cs + cc));
+          }
+          const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{TY(i - 1, j + 1), cn.y});
+          fNn[e] = vn * quick_face2(cs, cc, cn, XY(i, j + 2), vn, rok ? mC : 0, rok ? mCN : 0);
+          difv[e] = ce + cn - 4.f * cc + cw + cs;                           // :198-200
+#undef XY
+        }
+        {  // the last cell the lane owns in this row (a partial last lane owns fewer than C)
+          f2 last = fNn[0];
+#pragma unroll
+          for (int e = 1; e < C; ++e)
+            if (j0 + e <= m - 2) last = fNn[e];
+          fSw.x = lane_prev_keep(fSw.x, last.x);
+          fSw.y = lane_prev_keep(fSw.y, last.y);
+        }
+#pragma unroll
+        for (int e = 0; e < C; ++e) {
+          const int j = j0 + e;
+          if (j > m - 2) break;
+          if (xdbg & 16) {
+            oxv[e] = ccv[e].x + bxv[e];
+            oyv[e] = ccv[e].y + byv[e];
+            continue;
+          }
+          const f2 fW = fE2[e], fS = (e == 0) ? fSw : fNn[e > 0 ? e - 1 : 0];
+          const f2 adv = ((fW - fEn[e]) + (fS - fNn[e]));
+          const f2 o = (adv + nu * difv[e]) * dt + f2{bxv[e], byv[e]};              // :174-175
+          oxv[e] = o.x;
+          oyv[e] = o.y;
+          fE2[e] = fEn[e];
+        }
+        if (xdbg & 32) {
+          if (oxv[0] == 12345.678f) dx[i * m + j0] = oyv[0];  // keeps the values live, never taken
+        } else if (full) {
+          __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
+          __builtin_memcpy(dy + i * m + j0, oyv, sizeof(float) * C);
+        } else {
+#pragma unroll
+          for (int e = 0; e < C; ++e)
+            if (j0 + e <= m - 2) {
+              dx[i * m + j0 + e] = oxv[e];
+              dy[i * m + j0 + e] = oyv[e];
+            }
+        }
+      }
+    }
+#undef TX
+#undef TY
+  }
+  __syncthreads();
+}
+
+// BDIM.updateUP lines 118-120 restricted to the cells where it is not the identity:
+// del != 1 or del1 != 0 (|d| < eps, plus the solid interior).  Everywhere else
+// u = 1*F - ub*0 + 0*g == F.  Results are staged (scratch) before being scattered so that every
+// band cell sees the un-forced F of its neighbours, as the reference's whole-array expression does.
+__device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, float *scratch, float dphi1,
+                                    float dphi2) {
+  const int m = P.m;
+  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) {
+    const int k = G(P.band_x)[q];
+    const float del = G(P.delx)[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
+    float un = del * R - ub * (del + (-1.f));
+    const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
+    const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
+    const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
+    const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
+    const float g = 0.5f * (G(P.wnxx)[k] * (dE - dW) + G(P.wnyx)[k] * (dN - dS));
+    un = un + G(P.del1x)[k] * g;
+    scratch[q] = un;
+  }
+  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) {
+    const int k = G(P.band_y)[q];
+    const float del = G(P.dely)[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
+    float un = del * R - ub * (del + (-1.f));
+    const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
+    const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
+    const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
+    const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
+    const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
+    un = un + G(P.del1y)[k] * g;
+    scratch[P.nband_x + q] = un;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) fx[G(P.band_x)[q]] = scratch[q];
+  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) fy[G(P.band_y)[q]] = scratch[P.nband_x + q];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MG.smooth(4) without the trailing increment (MG.pde:80-89): d = r*inv, then four in-place
+// lexicographic Gauss-Seidel sweeps, in the reference's exact dependency order.
+//
+// One wave marches a strip of 16 rows along j.  Lane = 16*k + c: sweep k (0..3), row
+// i = I0 - k + c (the strip of sweep k is shifted up by k rows so that sweep k never overtakes
+// sweep k-1); at step tau the lane updates column j = tau - c - kLag*k + 1.  The four neighbours of
+// cell (i,j) in sweep k:
+//   d[i-1][j] (sweep k)   lane (k, c-1), one step earlier -> DPP row_shr:1   (c == 0: the row above, finished
+//                                                                             by the previous strip, in the ring)
+//   d[i][j-1] (sweep k)   this lane, one step earlier     -> register
+//   d[i+1][j] (sweep k-1) | stored IN PLACE in the d ring by the previous sweep kLag steps earlier (sweep 0: d0 =
+//   d[i][j+1] (sweep k-1) | r*inv from the fill) and overwritten by this very sweep one step later
+// which is what the sequential loops see, so every cell gets the reference's bits.  r and d live in 24-row LDS rings
+// that all four waves fill/drain with coalesced accesses; out-of-domain neighbours read as 0 (ghost d is 0 on the
+// finest level and multiplies a zero face coefficient on the coarse ones).
+// Coefficients: on strips that do not touch the bodies they are synthesised from the level's
+// analytic description (LevelDesc), otherwise loaded per cell.
+// (Round 1 exchanged the sweeps through registers -- lane-16 by two gfx950 row swaps, 8 of its 22 vector
+// instructions per step, one step of lag -- and kept the boundary rows of a strip in separate carry rows; the
+// in-place form below issues 10 vector + 2.5 LDS instructions per step and runs the finest level's march at 0.55 of
+// that time.  DESIGN.md section 3 has the stages and what bounds it now.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kRing = 24;
+
+// LDS layout used by the smoother (floats, PW = m + kPad):
+//   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][zero row PW][kPad][dummy row PW]
+__device__ __host__ __forceinline__ int gs_lds_floats(int m) {
+  return 36 /*kPad*/ + (2 * 24 /*kRing*/ + 2) * (m + 36) + 3 * 36;
+}
+
+// analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
+__device__ __forceinline__ void coef_analytic(const LevelDesc &D, const DescU &du, int i, int j, int n_, int m_,
+                                              float &lw, float &le, float &ls, float &ln, float &iv) {
+  if (!du.zb) {  // finest level: boundary faces keep c = dt, inv is the same everywhere
+    lw = le = ls = ln = du.cu;
+    iv = du.iv0;
+    return;
+  }
+  const float b = 0.f;
+  lw = (i == 1) ? b : du.cu;
+  le = (i == n_) ? b : du.cu;
+  ls = (j == 1) ? b : du.cu;
+  ln = (j == m_) ? b : du.cu;
+  iv = D.invtab[3 * ((i == 1) ? 1 : ((i == n_) ? 2 : 0)) + ((j == 1) ? 1 : ((j == m_) ? 2 : 0))];
+}
+
+// Ring rows are stored with pitch PW = m + kPad; the kPad trailing floats (and a kPad front pad of
+// each array) only ever receive zeros.  Running pointers are never clamped: a lane that is before
+// the first / past the last column of its row reads a pad, a lane whose row lies outside the grid
+// reads the all-zero row `zrow` and writes to `dummy`.  One unsigned compare per step forces the
+// result of such a lane to 0 (which is also what its neighbours must see: ghost d = 0); its writes
+// are unconditional -- zeros into a pad or the dummy row.
+constexpr int kPad = 36;  // >= 34: the last lanes run (and write zeros) up to column m_+35
+
+// The march.  EVERY sweep writes its result in place (as the sequential loops do) and reads d[i+1][j], d[i][j+1] of the
+// previous sweep from LDS; consecutive sweeps follow each other at kLag = 4 steps.  Right after steps e, e+1 of a
+// 4-step chunk have stored their values (one ds_write2_b32), the operands of the same two steps of the NEXT chunk are
+// fetched (ds_read2_b32): what they need was stored exactly kLag steps before their use, i.e. by the store just issued
+// (same wave: LDS operations execute in order), and the fetch has two to three steps to land.
+constexpr int kLag = 4;
+template <bool FAST, bool ZB = true>
+__device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0) {
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = m + kPad;
+  const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
+  const int i = I0 - k + c;
+  const bool row_ok = (i >= 1) && (i <= n_);
+  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);  // clamped for addressing only
+  const int slot = (ic % kRing) * PW, slotE = ((ic + 1) % kRing) * PW;
+  const LevelDesc &D = *L.desc;
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
+  if (FAST) {  // row-dependent part of the analytic inverse diagonal
+    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
+    iv0 = D.invtab[3 * rc + 0];
+    iv1 = D.invtab[3 * rc + 1];
+    iv2 = D.invtab[3 * rc + 2];
+  }
+  const float cu = uni(D.cu);
+  const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
+  // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
+  // iteration and possibly one more at the end
+  const int steps = (m_ + 15 + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
+  const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
+  // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
+  // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
+  // outside the grid read the zero row and write to the dummy row.
+  const int jo = 1 - c - kLag * k;
+  const float *p_rv = (row_ok ? rr + slot : zrow) + jo;
+  const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
+  const float *p_cW = (rowW_ok ? dr + ((i - 1) % kRing) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
+  const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
+  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
+  float *w_d = (row_ok ? dr + slot : dummy) + jo;
+  // The five streams of a lane as LDS byte addresses that advance by one opaque add per loop iteration (8 steps): every
+  // access below is `base + immediate`, two consecutive steps per instruction (ds_read2_b32 / ds_write2_b32).
+  unsigned q_rv = lds_addr(p_rv), q_cW = lds_addr(p_cW), q_cN = lds_addr(p_cN), q_dE = lds_addr(p_dE), q_wd = lds_addr(w_d);
+#define LD2(q, o) (*(const lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)))
+#define ST2(q, o, v) (*(lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)) = (v))
+  float aR[4], aW[4], aN[4], aE[4], bR[4], bW[4], bN[4], bE[4];
+#pragma unroll
+  for (int h = 0; h < 4; h += 2) {
+    const f2u r2 = LD2(q_rv, h), w2 = LD2(q_cW, h), n2 = LD2(q_cN, h), e2 = LD2(q_dE, h);
+    aR[h] = r2.x, aR[h + 1] = r2.y, aW[h] = w2.x, aW[h + 1] = w2.y;
+    aN[h] = n2.x, aN[h + 1] = n2.y, aE[h] = e2.x, aE[h + 1] = e2.y;
+  }
+  F4 a_lw, a_le, a_ls, a_iv, b_lw, b_le, b_ls, b_iv;
+  float a_ln4 = 0.f, b_ln4 = 0.f;
+  const int cbase = ic * m + jo;  // + tau = flat index of this lane's cell at step tau
+#define GS_CHUNK(TAU, lw_, le_, ls_, iv_, ln4_) \
+  {                                             \
+    int kk_ = cbase + (TAU);                    \
+    kk_ = kk_ < 0 ? 0 : kk_;                    \
+    lw_ = load4u(L.lx + kk_);                   \
+    le_ = load4u(L.lx + kk_ + m);               \
+    ls_ = load4u(L.ly + kk_);                   \
+    iv_ = load4u(L.inv + kk_);                  \
+    ln4_ = L.ly[kk_ + 4];                       \
+  }
+  if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
+  float res = 0.f;
+  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
+  // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
+  // fetched (what they need was stored kLag steps before its use, i.e. by the store just issued).  O = offset of the
+  // chunk from the iteration's base addresses; STEADY: no activity mask, interior inverse diagonal
+#define GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
+  _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                                                                   \
+    f2u out;                                                                                                           \
+    _Pragma("unroll") for (int e = h; e < h + 2; ++e) {                                                                \
+      float lw, le, ls, ln, iv;                                                                                        \
+      if (FAST) {                                                                                                      \
+        /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:       */ \
+        /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                     */ \
+        lw = le = ls = ln = cu;                                                                                        \
+        iv = iv0;                                                                                                      \
+        if (zb && !(STEADY)) {                                                                                         \
+          const int j = (T0) + jo + e;                                                                                 \
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                               \
+        }                                                                                                              \
+      } else {                                                                                                         \
+        lw = c_lw.v[e];                                                                                                \
+        le = c_le.v[e];                                                                                                \
+        ls = c_ls.v[e];                                                                                                \
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                    \
+        iv = c_iv.v[e];                                                                                                \
+      }                                                                                                                \
+      /* (k, c-1) holds sweep k at (i-1, j) one step earlier: DPP row_shr:1; c == 0 keeps cW = the row above, in the ring */ \
+      const float t = gs_core<FAST, FAST && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);            \
+      const float v = (FAST && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                             \
+      res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                             \
+      if (e == h) out.x = res; else out.y = res;                                                                       \
+    }                                                                                                                  \
+    ST2(q_wd, (O) + h, out);                                                                                           \
+    const f2u r2 = LD2(q_rv, (O) + 4 + h), w2 = LD2(q_cW, (O) + 4 + h);                                                \
+    const f2u n2 = LD2(q_cN, (O) + 4 + h), e2 = LD2(q_dE, (O) + 4 + h);                                                \
+    nR[h] = r2.x, nR[h + 1] = r2.y, nW[h] = w2.x, nW[h + 1] = w2.y;                                                    \
+    nN[h] = n2.x, nN[h + 1] = n2.y, nE[h] = e2.x, nE[h + 1] = e2.y;                                                    \
+  }
+#define GS3_CHUNK2(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, \
+                   n_ln4)                                                                                              \
+  {                                                                                                                    \
+    if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
+    GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
+  }
+#define GS3_ITER(STEADY)                                                                                               \
+  {                                                                                                                    \
+    GS3_CHUNK2(STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, \
+               b_ln4)                                                                                                  \
+    GS3_CHUNK2(STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls,   \
+               a_iv, a_ln4)                                                                                            \
+    /* opaque to the optimiser: the addresses are NOT re-derived from tau0 (one VALU add per access otherwise) */     \
+    asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
+                 "v_add_u32 %4, 32, %4"                                                                                \
+                 : "+v"(q_rv), "+v"(q_cW), "+v"(q_cN), "+v"(q_dE), "+v"(q_wd));                                        \
+  }
+  // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
+  // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
+  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
+  const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
+  int tau0 = 0;
+  for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
+  if (FAST)
+    for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
+  for (; tau0 < steps8; tau0 += 8) GS3_ITER(false)
+  if (tau0 < steps)
+    GS3_CHUNK2(false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
+#undef GS3_ITER
+#undef LD2
+#undef ST2
+#undef GS3_CHUNK2
+#undef GS3_STEPS
+#undef GS_CHUNK
+}
+
+// prolongate(coarse.x) at a (possibly ghost) cell of the fine level (MG.pde:139-152 incl. setBC)
+__device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc, int i, int j, int n_, int m_) {
+  const int ci = i < 1 ? 1 : (i > n_ ? n_ : i), cj = j < 1 ? 1 : (j > m_ ? m_ : j);
+  return xc[((ci - 1) / 2 + 1) * mc + ((cj - 1) / 2 + 1)];
+}
+
+// ---- the two per-chunk bodies of the up-leg (4 columns of one row), split into "issue the global
+// loads" and "compute" so that the finest level can issue the loads while the march is running ----
+struct UpGeom {
+  const Lv *F, *Cc;
+  const LevelDesc *D;
+  int n, m, n_, m_, mc, PW, CPR;
+  float *rr, *dr;
+  DescU du;
+  int NR = kRing;        // rows in the LDS rings (24 for the strip march, H + 6 for the multi-wave smoother)
+  bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
+  bool update_x = true;  // false: replay that only materialises r
+};
+struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
+  F4 r;
+  float a[4], w1, w2, e1, e2;
+};
+struct ExitIn {  // x of the chunk, the coarse x under it, the two x ghosts a boundary chunk mirrors into
+  F4 x;
+  float a1, a2, gl, gh;
+};
+
+__device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, int g, int c4) {
+  FillIn in;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) in.r.v[e] = in.a[e] = 0.f;
+  in.w1 = in.w2 = in.e1 = in.e2 = 0.f;
+  if (g <= U.n_) {
+    in.r = load4u(U.F->r + g * U.m + 1 + 4 * c4);
+    if (HASC) {
+      const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > U.n_) ? U.n_ : g + 1;
+      const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
+      const float *xw = U.Cc->x + ((gw - 1) / 2 + 1) * U.mc + 2 * c4;
+      const float *xe = U.Cc->x + ((ge - 1) / 2 + 1) * U.mc + 2 * c4;
+      // three 16-byte loads instead of eight dwords
+      const F4 va = load4u(xa), vw = load4u(xw), ve = load4u(xe);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) in.a[e] = va.v[e];
+      in.w1 = vw.v[1];
+      in.w2 = vw.v[2];
+      in.e1 = ve.v[1];
+      in.e2 = ve.v[2];
+    }
+  }
+  return in;
+}
+
+// r (after the prolongation increment) and d0 = r*inv of one chunk -> rings
+__device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int g, int c4, const FillIn &in, bool sp) {
+  const int m = U.m, n_ = U.n_, m_ = U.m_, CPR = U.CPR;
+  const int j = 1 + 4 * c4;
+  const int sl = (g % U.NR) * U.PW + j;
+  F4 rv = in.r, dv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dv.v[e] = 0.f;
+  if (g <= n_) {
+    const int kk = g * m + j;
+    F4 lw, le, ls, iv;
+    float ln4;
+    if (sp) {
+      lw = load4u(U.F->lx + kk);
+      le = load4u(U.F->lx + kk + m);
+      ls = load4u(U.F->ly + kk);
+      ln4 = U.F->ly[kk + 4];
+      iv = load4u(U.F->inv + kk);
+    } else {
+      float a0, a1, a2, a3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        coef_analytic(*U.D, U.du, g, j + e, n_, m_, a0, a1, a2, a3, iv.v[e]);
+        lw.v[e] = a0;
+        le.v[e] = a1;
+        ls.v[e] = a2;
+        if (e == 3) ln4 = a3;
+      }
+    }
+    if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+      const float a1 = in.a[1], a2 = in.a[2];
+      const float a0 = (c4 == 0) ? a1 : in.a[0], a3 = (c4 == CPR - 1) ? a2 : in.a[3];
+      const float w1 = in.w1, w2 = in.w2, e1 = in.e1, e2 = in.e2;
+      const float dc[4] = {a1, a1, a2, a2}, dw[4] = {w1, w1, w2, w2}, de[4] = {e1, e1, e2, e2};
+      const float ds[4] = {a0, a1, a1, a2}, dn[4] = {a1, a2, a2, a3};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+        rv.v[e] = rv.v[e] - (dc[e] * diag + dw[e] * lw.v[e] + de[e] * le.v[e] + ds[e] * ls.v[e] + dn[e] * lnv);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    U.rr[sl + e] = rv.v[e];
+    U.dr[sl + e] = dv.v[e];
+  }
+  if (c4 == 0) U.dr[sl - 1] = 0.f;  // ghost columns of d0 read as zero
+  if (c4 == CPR - 1) U.dr[sl + 4] = 0.f;
+}
+
+__device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, int g, int c4) {
+  ExitIn in;
+  const int kk = g * U.m + 1 + 4 * c4;
+  in.a1 = in.a2 = in.gl = in.gh = 0.f;
+  if (!U.update_x) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) in.x.v[e] = 0.f;
+    return in;
+  }
+  in.x = load4u(U.F->x + kk);
+  if (HASC) {
+    const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
+    float a12[2];
+    __builtin_memcpy(a12, xa + 1, 8);  // one 8-byte load
+    in.a1 = a12[0];
+    in.a2 = a12[1];
+  }
+  if (c4 == 0) in.gl = U.F->x[kk - 1];
+  if (c4 == U.CPR - 1) in.gh = U.F->x[kk + 4];
+  return in;
+}
+
+// d.setBC(); x += d (+ the ghosts that mirror the chunk); r -= A d   (MG.pde:90-97)
+__device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, const bool need_r, int g, int c4,
+                                           const ExitIn &in, bool sp, double &rr_part, double &xs_part, float &linf) {
+  const int n = U.n, m = U.m, n_ = U.n_, m_ = U.m_, CPR = U.CPR, PW = U.PW;
+  const Lv &F = *U.F;
+  float *rr = U.rr, *dr = U.dr;
+  const int j = 1 + 4 * c4, kk = g * m + j;
+  const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+  const int sl = (g % U.NR) * PW + j;
+  float dp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (HASC) {
+    dp[0] = in.a1;
+    dp[1] = in.a1;
+    dp[2] = in.a2;
+    dp[3] = in.a2;
+  }
+  float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
+#pragma unroll
+  for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
+  if (c4 == 0) d6[0] = d6[1];
+  if (c4 == CPR - 1) d6[5] = d6[4];
+  F4 xn;
+  if (need_r) {
+    const float *dwp = dr + (gw % U.NR) * PW + j, *dep = dr + (ge % U.NR) * PW + j;
+    F4 lw, le, ls;
+    float ln4;
+    if (sp) {
+      lw = load4u(F.lx + kk);
+      le = load4u(F.lx + kk + m);
+      ls = load4u(F.ly + kk);
+      ln4 = F.ly[kk + 4];
+    } else {
+      float a0, a1, a2, a3, a4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        coef_analytic(*U.D, U.du, g, j + e, n_, m_, a0, a1, a2, a3, a4);
+        lw.v[e] = a0;
+        le.v[e] = a1;
+        ls.v[e] = a2;
+        if (e == 3) ln4 = a3;
+      }
+    }
+    F4 rn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+      const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
+      const float d = d6[1 + e];
+      rn.v[e] = rr[sl + e] - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
+      const float pr = rn.v[e] * rn.v[e];
+      rr_part += (double)pr;
+      linf = jmax(linf, jabs(rn.v[e]));
+    }
+    if (U.store_r) store4u(F.r + kk, rn);
+  }
+  if (!U.update_x) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float xo = in.x.v[e];
+    if (HASC) xo = xo + dp[e];
+    xn.v[e] = xo + d6[1 + e];
+    if (need_r) xs_part += (double)xn.v[e];
+  }
+  store4u(F.x + kk, xn);
+  // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
+  if (c4 == 0) {
+    float xg = in.gl;
+    if (HASC) xg = xg + dp[0];
+    F.x[kk - 1] = xg + d6[1];
+  }
+  if (c4 == CPR - 1) {
+    float xg = in.gh;
+    if (HASC) xg = xg + dp[3];
+    F.x[kk + 4] = xg + d6[4];
+  }
+  if (g == 1 || g == n_) {
+    const int kg = ((g == 1) ? 0 : (n - 1)) * m + j;
+    const F4 xg4 = load4u(F.x + kg);
+    F4 xgn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xg = xg4.v[e];
+      if (HASC) xg = xg + dp[e];
+      xgn.v[e] = xg + d6[1 + e];
+    }
+    store4u(F.x + kg, xgn);
+    if (c4 == 0) {
+      float xg = F.x[kg - 1];
+      if (HASC) xg = xg + dp[0];
+      F.x[kg - 1] = xg + d6[1];
+    }
+    if (c4 == CPR - 1) {
+      float xg = F.x[kg + 4];
+      if (HASC) xg = xg + dp[3];
+      F.x[kg + 4] = xg + d6[4];
+    }
+  }
+}
+
+// One call = everything a level does on the way up (MG.pde:73-76 seen from the level itself):
+//   HASC:  d = prolongate(coarse.x); increment()            [x += d, r -= A d]
+//   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
+// streamed strip by strip: r (and p on the finest level) cross HBM once, d never leaves LDS.
+// need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
+__device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                    float *rr_out,
+                                    float *linf_out, ProfT &pf, float *xsum_out = nullptr, const int rmode = 0) {
+  // rmode (finest level, chunked path): 0 = r written back; 1 = r not written back (the caller replays
+  // with rmode 2 in the rare case a second V-cycle needs it); 2 = replay: same d, only r is stored
+  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
+  const int PW = m + kPad;
+  const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));  // diagnostics: phase marks for the level with n rows
+  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
+  const int tid = threadIdx.x;
+  const LevelDesc &D = *F.desc;
+  const int mc = Cc.m;
+  const int rstep = kThreads / m, cstep = kThreads - rstep * m;  // flat (row, col) stepping by kThreads
+  const int r0 = tid / m, c0 = tid - r0 * m;
+  double rr_part = 0, xs_part = 0;
+  float linf = 0.f;
+  const int CPR = m_ >> 2;
+  const bool chunked = ((m_ & 3) == 0);
+  const DescU du = desc_u(D);
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
+  U.store_r = (rmode != 1);
+  U.update_x = (rmode != 2);
+  // a thread keeps its 4-column chunk and walks down the rows of its group: no integer division in the strip loops
+  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
+  const bool grp_on = chunked && (rg < ngrp);
+  __syncthreads();
+  // zero everything once: pads and the zero row (ring interiors are overwritten by the fills)
+  // (the region is shared with the other phases' tiles, so this is redone on every call)
+  for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
+  lds_barrier();
+  int loaded = 0;  // rows 1..loaded are (or were) in the rings
+  for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
+    // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
+    const int hi = I0 + 16;
+    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
+    if (chunked) {
+      // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
+      if (grp_on)
+        for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+          const FillIn in = fill_load(U, HASC, g, c4);
+          fill_apply(U, HASC, g, c4, in, sp_fill);
+        }
+    } else
+    {
+      int g = loaded + 1 + r0, j = c0;
+      while (g <= hi) {
+        float rv = 0.f, dv = 0.f;
+        if (g <= n_ && j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          rv = F.r[kk];
+          float lw, le, ls, ln, iv;
+          if (sp_fill) {
+            lw = F.lx[kk];
+            le = F.lx[kk + m];
+            ls = F.ly[kk];
+            ln = F.ly[kk + 1];
+            iv = F.inv[kk];
+          } else {
+            coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+          }
+          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+            const float dc = prolong_at(Cc.x, mc, g, j, n_, m_);
+            const float dw = prolong_at(Cc.x, mc, g - 1, j, n_, m_), de = prolong_at(Cc.x, mc, g + 1, j, n_, m_);
+            const float ds = prolong_at(Cc.x, mc, g, j - 1, n_, m_), dn = prolong_at(Cc.x, mc, g, j + 1, n_, m_);
+            const float diag = -(lw + le + ls + ln);
+            rv = rv - (dc * diag + dw * lw + de * le + ds * ls + dn * ln);
+          }
+          dv = rv * iv;  // MG.pde:80
+        }
+        const int sl = (g % kRing) * PW + j;
+        rr[sl] = rv;
+        dr[sl] = dv;
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    loaded = hi;
+    lds_barrier();
+    if (mk) pf.mark(PF_UP0);
+    if (tid < 64) {
+      const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
+      __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
+      if (special)
+        gs_march3<false>(F, rr, dr, zrow, dummy, I0);
+      else if (du.zb)
+        gs_march3<true, true>(F, rr, dr, zrow, dummy, I0);
+      else
+        gs_march3<true, false>(F, rr, dr, zrow, dummy, I0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    lds_barrier();
+    if (mk) pf.mark(PF_GS0);
+    // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
+    const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
+    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
+    if (chunked) {
+      if (grp_on)
+        for (int g = e0 + rg; g <= e1; g += ngrp) {
+          const ExitIn in = exit_load(U, HASC, g, c4);
+          exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+        }
+    } else
+    {
+      int g = e0 + r0, j = c0;
+      while (g <= e1) {
+        if (j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+          const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
+          const int sl = (g % kRing) * PW;
+          const float d = dr[sl + j];
+          if (need_r) {
+            const float dW = dr[(gw % kRing) * PW + j], dE = dr[(ge % kRing) * PW + j];
+            const float dS = dr[sl + js], dN = dr[sl + jn];
+            float lw, le, ls, ln, iv;
+            if (sp_exit) {
+              lw = F.lx[kk];
+              le = F.lx[kk + m];
+              ls = F.ly[kk];
+              ln = F.ly[kk + 1];
+            } else {
+              coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+            }
+            const float diag = -(lw + le + ls + ln);
+            const float rn = rr[sl + j] - (d * diag + dW * lw + dE * le + dS * ls + dN * ln);  // MG.pde:96
+            F.r[kk] = rn;
+            const float pr = rn * rn;
+            rr_part += (double)pr;
+            linf = jmax(linf, jabs(rn));
+          }
+          // x += d on the cell and on the ghosts that mirror it (MG.pde:95 after d.setBC())
+          float xo = F.x[kk];
+          if (HASC) xo = xo + prolong_at(Cc.x, mc, g, j, n_, m_);
+          const float xnew = xo + d;
+          F.x[kk] = xnew;
+          if (need_r) xs_part += (double)xnew;
+          const bool gi0 = (g == 1), gi1 = (g == n_), gj0 = (j == 1), gj1 = (j == m_);
+          if (gi0 | gi1 | gj0 | gj1) {
+            const float dp = HASC ? prolong_at(Cc.x, mc, g, j, n_, m_) : 0.f;
+#define GHOST_UPD(GI, GJ)                        \
+  {                                              \
+    float xg = F.x[(GI) * m + (GJ)];             \
+    if (HASC) xg = xg + dp;                      \
+    F.x[(GI) * m + (GJ)] = xg + d;               \
+  }
+            if (gi0) GHOST_UPD(0, j)
+            if (gi1) GHOST_UPD(n - 1, j)
+            if (gj0) GHOST_UPD(g, 0)
+            if (gj1) GHOST_UPD(g, m - 1)
+            if (gi0 && gj0) GHOST_UPD(0, 0)
+            if (gi0 && gj1) GHOST_UPD(0, m - 1)
+            if (gi1 && gj0) GHOST_UPD(n - 1, 0)
+            if (gi1 && gj1) GHOST_UPD(n - 1, m - 1)
+#undef GHOST_UPD
+          }
+        }
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
+    if (mk) pf.mark(PF_INC0);
+  }
+  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
+  if (need_r && rmode != 2) {
+    *rr_out = uni((float)block_sum_d(rr_part, sm));
+    *linf_out = uni(block_max_f(linf, sm));
+    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+  }
+}
+
+// =============================================================================================
+// Multi-wave hyperplane smoother: MG.smooth(4) (MG.pde:79-92) with ALL FOUR WAVES of the workgroup.
+//
+// Wave k runs sweep k; lane l (1..H) of wave k owns row i = I0 - k - 1 + l of a strip of H rows (the strip of
+// sweep k is shifted up by k rows, so sweep k never needs a row its predecessor has not finished), lane 0 re-plays
+// row I0 - k - 1, which the previous strip finished, so that every real lane finds d[i-1][j] in lane-1.
+// At global step tau the lane is at column j = tau - l - S*k + 1.  The four neighbours of cell (i,j) in sweep k:
+//   d[i-1][j] (sweep k)   computed one step earlier by lane l-1  -> DPP wave_shr:1
+//   d[i][j-1] (sweep k)   computed one step earlier by this lane -> register
+//   d[i+1][j] (sweep k-1) | both were written to the LDS array D by wave k-1 exactly S steps earlier (k == 0: d0 =
+//   d[i][j+1] (sweep k-1) | r*inv left there by the fill) and are overwritten by this very sweep one step LATER
+// which is the order the sequential loops of the reference see, so every cell gets the reference's bits.
+// Steps are grouped in chunks of 4 with ONE LDS barrier per chunk: a chunk reads its operands from LDS one chunk
+// ahead, computes 4 steps in registers and writes its 4 results; S = 8 guarantees that what a chunk prefetches was
+// written at least one barrier earlier (4q+e+4-S <= 4q-1) and that nothing it still needs has been overwritten.
+// D and R (r after the prolongation increment) are rings of NR = H + 6 full-width rows; r is read-only here.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMwS = 8;
+constexpr int kMwGuardLo = 96, kMwGuardMid = 160;  // lanes outside their row read (and ignore) whatever lies there
+
+__device__ __host__ __forceinline__ int mw_lds_floats(int m, int H) {
+  return kMwGuardLo + 2 * ((H + 6) * m + kMwGuardMid) + 64 + 8;
+}
+
+__device__ __forceinline__ float lane_prev(float v) {  // the value lane-1 holds (whole wave); lane 0 gets 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_next(float v) {  // the value lane+1 holds (whole wave); lane 63 gets 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+
+// dst = (lane is a re-play lane) ? b : a, as one v_cndmask on a constant lane mask (kept opaque: written as a C
+// select the compiler predicates the whole update on it and pays an exec-mask branch per step)
+__device__ __forceinline__ float sel_mask(float a, float b, unsigned long long mk) {
+  float r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mk));
+  return r;
+}
+
+// PER = sweeps per wave.  PER 1: wave k = sweep k, up to 62 rows per strip.  PER 2: waves 0 and 1 carry two sweeps
+// each (lanes 0-31 / 32-63), up to 30 rows per strip -- the form for the finest level, whose strips are LDS-bound
+// to ~28 rows: half the instruction streams for the same step count.  Waves wait for each other through progress
+// words in LDS (a wave publishes the number of the chunk it has finished; the next sweep's wave checks it before it
+// prefetches), not through workgroup barriers: LDS operations of one wave execute in order, so a consumer that sees
+// the progress word also sees the data written before it.
+// Not inlined on purpose: every instantiation gets its own register allocation instead of inflating the live ranges
+// of the phases around it.
+template <bool FAST, bool ZB, int PER>
+__device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *Dg, float *dummyg, int NR, int I0,
+                                          int Lmax, int gbase) {
+  const int wave = threadIdx.x >> 6;
+  if (PER == 2 && wave >= 2) return;
+  const lds_f *R = (const lds_f *)Rg;
+  lds_f *D = (lds_f *)Dg;
+  lds_f *dummy = (lds_f *)dummyg;
+  volatile lds_i *prog = (volatile lds_i *)(dummy + 64);  // [4] progress words
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
+  const int lane64 = threadIdx.x & 63;
+  const int lane = (PER == 2) ? (lane64 & 31) : lane64;
+  const int k = (PER == 2) ? (2 * wave + (lane64 >> 5)) : wave;
+  const unsigned long long replay = (PER == 2) ? 0x100000001ull : 1ull;
+  const int i = I0 - k - 1 + lane;
+  const bool rowin = (i >= 1) && (i <= n_);
+  const bool is0 = (lane == 0);
+  const bool real = rowin && !is0 && (lane <= Lmax);
+  const unsigned m_on = (real || (rowin && is0)) ? (unsigned)m_ : 0u;  // columns 1..m_on produce a value
+  const unsigned m_wr = real ? (unsigned)m_ : 0u;                     // ... and are stored
+  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);
+  const int so = (ic % NR) * m;
+  const int se = is0 ? so : ((ic + 1) % NR) * m;  // re-play lanes fetch their own (finished) row through the east stream
+  const int jo = 1 - lane - kMwS * k;
+  const LevelDesc &Dsc = *L.desc;
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
+  if (FAST) {
+    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
+    iv0 = Dsc.invtab[3 * rc + 0];
+    iv1 = Dsc.invtab[3 * rc + 1];
+    iv2 = Dsc.invtab[3 * rc + 2];
+  }
+  const float cu = uni(Dsc.cu);
+  const int T = (m_ + Lmax + 3 * kMwS + 7) & ~7;  // two chunks per loop iteration
+  const lds_f *pR = R + so + jo, *pE = D + se + jo, *pN = D + so + jo + 1;
+  lds_f *pW = D + so + jo;
+  lds_f *dmy = dummy + lane64;
+  float aR[4], aE[4], aN[4], bR[4], bE[4], bN[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    aR[e] = pR[e];
+    aE[e] = pE[e];
+    aN[e] = pN[e];
+  }
+  // coefficients of the strips that touch a body: four columns per 16-byte load, one chunk ahead.  The east face
+  // lx[i+1][j] is the west face of the row below, i.e. what lane+1 (one column behind) holds: no load for it.
+  F4 a_lw, a_ls, a_iv, b_lw, b_ls, b_iv;
+  float a_ln4 = 0.f, b_ln4 = 0.f;
+  const int icf = i < 0 ? 0 : (i > n_ + 1 ? n_ + 1 : i);  // every lane loads its own row (also the one below the strip)
+  const int cbase = icf * m + jo;
+#define MW_COEF(TAU, lw_, ls_, iv_, ln4_) \
+  {                                       \
+    int kk_ = cbase + (TAU);              \
+    kk_ = kk_ < 0 ? 0 : kk_;              \
+    lw_ = load4u(L.lx + kk_);             \
+    ls_ = load4u(L.ly + kk_);             \
+    iv_ = load4u(L.inv + kk_);            \
+    ln4_ = L.ly[kk_ + 4];                 \
+  }
+  if (!FAST) MW_COEF(0, a_lw, a_ls, a_iv, a_ln4)
+  float cur = 0.f;
+  const bool consumer = (wave > 0);
+  volatile lds_i *pprod = prog + (wave > 0 ? wave - 1 : 0);
+  int seen = gbase - 1;
+  if (consumer) __builtin_amdgcn_s_sleep(8);  // start about one chunk behind the producer: its progress word is then
+                                              // normally ahead of what is asked for and nobody spins
+  // one chunk: prefetch the operands of the next chunk into (nR,nE,nN / n_*), run 4 steps on (cR,cE,cN / c_*)
+#define MW_CHUNK(TAU0, cR, cE, cN, nR, nE, nN, c_lw, c_ls, c_iv, c_ln4, n_lw, n_ls, n_iv, n_ln4)                  \
+  {                                                                                                               \
+    const int tau0_ = (TAU0);                                                                                     \
+    const int q_ = tau0_ >> 2;                                                                                    \
+    if (consumer && q_ >= 1) { /* the previous sweep must have finished chunk q-1 (S = 8) */                      \
+      const int need_ = gbase + q_ - 1;                                                                           \
+      while (seen < need_) {                                                                                      \
+        __builtin_amdgcn_s_sleep(1);                                                                              \
+        seen = *pprod;                                                                                            \
+      }                                                                                                           \
+    }                                                                                                             \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+      nR[e] = pR[tau0_ + 4 + e];                                                                                  \
+      nE[e] = pE[tau0_ + 4 + e];                                                                                  \
+      nN[e] = pN[tau0_ + 4 + e];                                                                                  \
+    }                                                                                                             \
+    if (consumer) seen = *pprod; /* for the next chunk: usually already far enough */                             \
+    float le4[4] = {0.f, 0.f, 0.f, 0.f};                                                                          \
+    if (!FAST) {                                                                                                  \
+      MW_COEF(tau0_ + 4, n_lw, n_ls, n_iv, n_ln4)                                                                 \
+      le4[0] = lane_next(c_lw.v[1]);                                                                              \
+      le4[1] = lane_next(c_lw.v[2]);                                                                              \
+      le4[2] = lane_next(c_lw.v[3]);                                                                              \
+      le4[3] = lane_next(n_lw.v[0]);                                                                              \
+    }                                                                                                             \
+    const int jb = tau0_ + jo;                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+      float lw, le, ls, ln, iv;                                                                                   \
+      if (FAST) { /* out-of-domain neighbours read as d = 0: a boundary face may keep the uniform coefficient */  \
+        lw = le = ls = ln = cu;                                                                                   \
+        iv = iv0;                                                                                                 \
+        if (ZB) {                                                                                                 \
+          const int j = jb + e;                                                                                   \
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                          \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        lw = c_lw.v[e];                                                                                           \
+        le = le4[e];                                                                                              \
+        ls = c_ls.v[e];                                                                                           \
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                               \
+        iv = c_iv.v[e];                                                                                           \
+      }                                                                                                           \
+      const float prev = cur;                                                                                     \
+      const float dW = lane_prev(prev);                                                                           \
+      const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv; /* MG.pde:84-88 */          \
+      const float v2 = sel_mask(v, cE[e], replay);                                                                \
+      cur = ((unsigned)(jb + e - 1) < m_on) ? v2 : 0.f;                                                           \
+      lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0_ + e) : dmy;                                        \
+      *w = cur;                                                                                                   \
+    }                                                                                                             \
+    asm volatile("" ::: "memory"); /* the progress word goes out after the data */                                \
+    if (lane64 == 0) prog[wave] = gbase + q_;                                                                     \
+    asm volatile("" ::: "memory");                                                                                \
+  }
+  for (int tau0 = 0; tau0 < T; tau0 += 8) {
+    MW_CHUNK(tau0, aR, aE, aN, bR, bE, bN, a_lw, a_ls, a_iv, a_ln4, b_lw, b_ls, b_iv, b_ln4)
+    MW_CHUNK(tau0 + 4, bR, bE, bN, aR, aE, aN, b_lw, b_ls, b_iv, b_ln4, a_lw, a_ls, a_iv, a_ln4)
+  }
+#undef MW_CHUNK
+#undef MW_COEF
+}
+
+// One call = everything a level does on the way up, like mg_up_smooth, with the multi-wave smoother: strips of
+// H rows (H = LevelDesc.mw_H, chosen on the host so that both rings fit the workgroup's LDS).
+__device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                       float *rr_out, float *linf_out, ProfT &pf, float *xsum_out = nullptr,
+                                       const int rmode = 0) {
+  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
+  const LevelDesc &D = *F.desc;
+  const int H = uni(D.mw_H), NR = H + 6;
+  float *dr = lds + kMwGuardLo, *rr = dr + NR * m + kMwGuardMid, *dummy = rr + NR * m + kMwGuardMid;
+  const int tid = threadIdx.x;
+  const int mc = Cc.m;
+  const int PW = m;
+  const int rstep = kThreads / m, cstep = kThreads - rstep * m;
+  const int r0 = tid / m, c0 = tid - r0 * m;
+  double rr_part = 0, xs_part = 0;
+  float linf = 0.f;
+  const int CPR = m_ >> 2;
+  const bool chunked = ((m_ & 3) == 0);
+  const DescU du = desc_u(D);
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
+  U.NR = NR;
+  U.store_r = (rmode != 1);
+  U.update_x = (rmode != 2);
+  // a thread keeps its 4-column chunk and walks down the rows of its group: no division in the strip loops
+  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
+  const bool grp_on = chunked && (rg < ngrp);
+  __syncthreads();
+  int gbase = 0;
+  if (tid < 4) ((lds_i *)(lds_f *)dummy)[64 + tid] = -1;  // progress words of the four waves
+  int loaded = 0;
+  for (int I0 = 1; I0 - 3 <= n_; I0 += H) {
+    const int hi = I0 + H;
+    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
+    if (chunked) {
+      if (grp_on)
+        for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+          const FillIn in = fill_load(U, HASC, g, c4);
+          fill_apply(U, HASC, g, c4, in, sp_fill);
+        }
+    } else {
+      int g = loaded + 1 + r0, j = c0;
+      while (g <= hi) {
+        float rv = 0.f, dv = 0.f;
+        if (g <= n_ && j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          rv = F.r[kk];
+          float lw, le, ls, ln, iv;
+          if (sp_fill) {
+            lw = F.lx[kk];
+            le = F.lx[kk + m];
+            ls = F.ly[kk];
+            ln = F.ly[kk + 1];
+            iv = F.inv[kk];
+          } else {
+            coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+          }
+          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
+            const float dc = prolong_at(Cc.x, mc, g, j, n_, m_);
+            const float dw = prolong_at(Cc.x, mc, g - 1, j, n_, m_), de = prolong_at(Cc.x, mc, g + 1, j, n_, m_);
+            const float ds = prolong_at(Cc.x, mc, g, j - 1, n_, m_), dn = prolong_at(Cc.x, mc, g, j + 1, n_, m_);
+            const float diag = -(lw + le + ls + ln);
+            rv = rv - (dc * diag + dw * lw + de * le + ds * ls + dn * ln);
+          }
+          dv = rv * iv;  // MG.pde:80
+        }
+        const int sl = (g % NR) * PW + j;
+        rr[sl] = rv;
+        dr[sl] = dv;
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    loaded = hi;
+    lds_barrier();
+    if (need_r) pf.mark(PF_UP0);
+    {
+      const int lm = n_ - I0 + 4, Lmax = lm < H ? lm : H;
+      const bool special = (hi >= du.sp_i0) && (I0 - 4 <= du.sp_i1);
+      gbase += 4096;  // chunk numbers never repeat within a level call, so the progress words need no reset
+      if (H <= 30) {  // two sweeps per wave
+        if (special)
+          gs_multiwave<false, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else if (du.zb)
+          gs_multiwave<true, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else
+          gs_multiwave<true, false, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+      } else {
+        if (special)
+          gs_multiwave<false, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else if (du.zb)
+          gs_multiwave<true, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+        else
+          gs_multiwave<true, false, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
+      }
+      lds_barrier();  // every sweep of the strip is complete
+    }
+    if (need_r) pf.mark(PF_GS0);
+    // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
+    const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + H - 4 >= n_) ? n_ : I0 + H - 5;
+    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
+    if (chunked) {
+      if (grp_on)
+        for (int g = e0 + rg; g <= e1; g += ngrp) {
+          const ExitIn in = exit_load(U, HASC, g, c4);
+          exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+        }
+    } else {
+      int g = e0 + r0, j = c0;
+      while (g <= e1) {
+        if (j >= 1 && j <= m_) {
+          const int kk = g * m + j;
+          const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
+          const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
+          const int sl = (g % NR) * PW;
+          const float d = dr[sl + j];
+          if (need_r) {
+            const float dW = dr[(gw % NR) * PW + j], dE = dr[(ge % NR) * PW + j];
+            const float dS = dr[sl + js], dN = dr[sl + jn];
+            float lw, le, ls, ln, iv;
+            if (sp_exit) {
+              lw = F.lx[kk];
+              le = F.lx[kk + m];
+              ls = F.ly[kk];
+              ln = F.ly[kk + 1];
+            } else {
+              coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
+            }
+            const float diag = -(lw + le + ls + ln);
+            const float rn = rr[sl + j] - (d * diag + dW * lw + dE * le + dS * ls + dN * ln);  // MG.pde:96
+            F.r[kk] = rn;
+            const float pr = rn * rn;
+            rr_part += (double)pr;
+            linf = jmax(linf, jabs(rn));
+          }
+          float xo = F.x[kk];
+          if (HASC) xo = xo + prolong_at(Cc.x, mc, g, j, n_, m_);
+          const float xnew = xo + d;
+          F.x[kk] = xnew;
+          if (need_r) xs_part += (double)xnew;
+          const bool gi0 = (g == 1), gi1 = (g == n_), gj0 = (j == 1), gj1 = (j == m_);
+          if (gi0 | gi1 | gj0 | gj1) {
+            const float dp = HASC ? prolong_at(Cc.x, mc, g, j, n_, m_) : 0.f;
+#define GHOST_UPD(GI, GJ)            \
+  {                                  \
+    float xg = F.x[(GI) * m + (GJ)]; \
+    if (HASC) xg = xg + dp;          \
+    F.x[(GI) * m + (GJ)] = xg + d;   \
+  }
+            if (gi0) GHOST_UPD(0, j)
+            if (gi1) GHOST_UPD(n - 1, j)
+            if (gj0) GHOST_UPD(g, 0)
+            if (gj1) GHOST_UPD(g, m - 1)
+            if (gi0 && gj0) GHOST_UPD(0, 0)
+            if (gi0 && gj1) GHOST_UPD(0, m - 1)
+            if (gi1 && gj0) GHOST_UPD(n - 1, 0)
+            if (gi1 && gj1) GHOST_UPD(n - 1, m - 1)
+#undef GHOST_UPD
+          }
+        }
+        g += rstep;
+        j += cstep;
+        if (j >= m) {
+          j -= m;
+          ++g;
+        }
+      }
+    }
+    lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
+    if (need_r) pf.mark(PF_INC0);
+  }
+  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
+  if (need_r && rmode != 2) {
+    *rr_out = uni((float)block_sum_d(rr_part, sm));
+    *linf_out = uni(block_max_f(linf, sm));
+    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused head of the pressure solve on the finest level (MG.pde:51 + first smooth(0) + restrict):
+//   r0 = div(u) - A (p+s)      s = pending mean shift of the previous projection (see project_v2)
+//   d  = r0*inv; d.setBC();    pout = (p+s) + d   (all cells incl. ghosts);   r = r0 - A d
+//   r1 = restrict(r)           (interior; coarse ghosts are never read)
+// Streamed in blocks of 14 rows: r0 of 16 rows goes through an LDS tile, every thread then owns
+// a 2x4 patch (one restriction pair of rows, two coarse cells).  u, v, p are read once, p and r
+// written once.  pin and pout are different buffers (rows a-2.. of pin are still needed when rows
+// ..a-1 of pout are written).
+// ---------------------------------------------------------------------------------------------
+// RESID = true : finest level, first iteration: r0 = div(u) - A (pin+s), x_out = (pin+s) + d
+// RESID = false: any level with an existing residual: r0 = F.r, x_out = F.x + d  (F.x is 0 on
+//                coarse levels, MG.pde:56; on the finest level it is the current iterate)
+// LDS: two tiles of TR = R+2 rows (global rows a-1 .. a+R), pitch PT = m+2 floats, a cell of column j at index j+3 so
+// that a thread's four columns 1+4c..4+4c are one aligned 16-byte access: `tr` holds r0, `td` holds d = r0*inv WITH the
+// setBC mirror written into its ghost columns and rows, so that the patches read their 4x6 window of d without any
+// clamping, computed once per cell.  Threads keep their 4-column chunk c4 and walk down rows / row pairs: no division
+// inside the loops.
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+typedef __attribute__((address_space(3))) f4a lds_f4;
+template <bool RESID, bool XZ>
+__device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+                                     const float *__restrict__ uy, const float *__restrict__ pin, float shift,
+                                     float *lds) {
+  const int n = L0.n, m = L0.m, n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  const LevelDesc &D = *L0.desc;
+  float *pout = L0.x, *r = L0.r;
+  if (!RESID) {
+    pin = L0.x;
+    shift = 0.f;
+  }
+  shift = uni(shift);
+  const int tid = threadIdx.x;
+  const int m1 = L1.m;
+  const DescU du = desc_u(D);
+  const bool unif = (du.zb == 0);  // finest level: all coefficients uniform outside the special rows
+  // rows per block: 14 on the finest grids; on narrow (coarse) levels enough rows to give every
+  // thread a patch (7*k*CPR patches per block), bounded by the 2080-float tile
+  const int PT = m + 2;
+  int kblk = 1;
+  if (!RESID && !(AFC_DBG_OF(P) & 1)) {
+    kblk = 32 / (CPR > 0 ? CPR : 1);
+    if (kblk < 1) kblk = 1;
+    while (kblk > 1 && (14 * kblk + 2) * PT > 2112) --kblk;
+  }
+  const int R = 14 * kblk, TR = R + 2, NPAIR = 7 * kblk;
+  // 16-byte aligned tiles; index of (tile row t, column j) = t*PT + j + 3
+  const unsigned lbase = (lds_addr(lds) + 15u) & ~15u;
+  const unsigned a_tr = lbase, a_td = lbase + 4u * (unsigned)(TR * PT + 4);
+#define T_R4(t, c) (*(lds_f4 *)(uintptr_t)(a_tr + 4u * (unsigned)((t) * PT + 4 * (c) + 4)))
+#define T_D4(t, c) (*(lds_f4 *)(uintptr_t)(a_td + 4u * (unsigned)((t) * PT + 4 * (c) + 4)))
+#define T_D1(t, j) (*(lds_f *)(uintptr_t)(a_td + 4u * (unsigned)((t) * PT + (j) + 3)))
+  const int ngrp = kThreads / CPR, rg = tid / CPR, c4 = tid - rg * CPR;  // the only divisions of the call
+  const bool on = rg < ngrp;
+  const int j = 1 + 4 * c4;
+  for (int a = 1; a <= n_; a += R) {
+    const bool sp = (a + R + 1 >= du.sp_i0) && (a - 2 <= du.sp_i1);
+    lds_barrier();
+    // ---- step 1: r0 and d = r0*inv for rows a-1 .. a+R ----
+    if (on)
+      for (int t = rg; t < TR; t += ngrp) {
+        const int g = a - 1 + t;
+        if (g < 1 || g > n_) continue;
+        if (!RESID && t == 0) continue;  // row a-1 was overwritten by the previous block: kept in the tiles
+        const int k = g * m + j;
+        F4 r0;
+        if (RESID) {
+          const F4 uxc = load4u(ux + k), uxe = load4u(ux + k + m), uyc = load4u(uy + k);
+          const float uyn = uy[k + 4];
+          const F4 pc = load4u(pin + k), pw = load4u(pin + k - m), pe = load4u(pin + k + m);
+          const float psl = pin[k - 1], pnr = pin[k + 4];
+          F4 lw, le, ls;
+          float ln4;
+          if (sp) {
+            lw = load4u(L0.lx + k);
+            le = load4u(L0.lx + k + m);
+            ls = load4u(L0.ly + k);
+            ln4 = L0.ly[k + 4];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+            ln4 = du.cu;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
+            const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
+            const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+            const float diag = -(lwv + lev + lsv + lnv);
+            const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
+            const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift,
+                        pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
+            const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
+            r0.v[e] = div - ap;
+          }
+        } else {
+          r0 = load4u(r + k);
+        }
+        F4 iv;
+        if (sp) {
+          iv = load4u(L0.inv + k);
+        } else if (unif) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) iv.v[e] = du.iv0;
+        } else {
+          const int rc = 3 * ((g == 1) ? 1 : ((g == n_) ? 2 : 0));
+          const float i0 = D.invtab[rc];
+          iv.v[0] = (c4 == 0) ? D.invtab[rc + 1] : i0;
+          iv.v[1] = i0;
+          iv.v[2] = i0;
+          iv.v[3] = (c4 == CPR - 1) ? D.invtab[rc + 2] : i0;
+        }
+        f4a r4, d4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          r4[e] = r0.v[e];
+          d4[e] = r0.v[e] * iv.v[e];  // MG.pde:80
+        }
+        T_R4(t, c4) = r4;
+        T_D4(t, c4) = d4;
+        // d.setBC(): ghosts mirror the adjacent interior cell (Field.pde:211-224)
+        if (c4 == 0) T_D1(t, 0) = d4[0];
+        if (c4 == CPR - 1) T_D1(t, m_ + 1) = d4[3];
+        if (g == 1 || g == n_) {
+          const int tg = (g == 1) ? t - 1 : t + 1;
+          if (tg >= 0 && tg < TR) {
+            T_D4(tg, c4) = d4;
+            if (c4 == 0) T_D1(tg, 0) = d4[0];
+            if (c4 == CPR - 1) T_D1(tg, m_ + 1) = d4[3];
+          }
+        }
+      }
+    lds_barrier();
+    // ---- step 2: one 2x4 patch per thread ----
+    if (on)
+      for (int pr = rg; pr < NPAIR; pr += ngrp) {
+        const int g = a + 2 * pr;
+        if (g > n_) continue;
+        const int tq = g - (a - 1);  // tile row of g
+        // d on rows g-1..g+2, cols j-1..j+4
+        float dd[4][6];
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+          const f4a v = T_D4(tq - 1 + a4, c4);
+          dd[a4][0] = T_D1(tq - 1 + a4, j - 1);
+          dd[a4][1] = v[0], dd[a4][2] = v[1], dd[a4][3] = v[2], dd[a4][4] = v[3];
+          dd[a4][5] = T_D1(tq - 1 + a4, j + 4);
+        }
+        float rn[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gg = g + h, k = gg * m + j;
+          F4 lw, le, ls;
+          float ln4;
+          if (sp) {
+            lw = load4u(L0.lx + k);
+            le = load4u(L0.lx + k + m);
+            ls = load4u(L0.ly + k);
+            ln4 = L0.ly[k + 4];
+          } else if (unif) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = du.cu;
+            ln4 = du.cu;
+          } else {
+            float a0, a1, a2, a3, a4v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              coef_analytic(D, du, gg, j + e, n_, m_, a0, a1, a2, a3, a4v);
+              lw.v[e] = a0;
+              le.v[e] = a1;
+              ls.v[e] = a2;
+              if (e == 3) ln4 = a3;
+            }
+          }
+          F4 pc;  // x before the increment: the iterate on the finest level, exactly zero on coarse ones (MG.pde:56)
+          if (!XZ) {
+            pc = load4u(pin + k);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pc.v[e] = 0.f;
+          }
+          const f4a r0row = T_R4(tq + h, c4);
+          F4 xo, ro;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+            const float diag = -(lwv + lev + lsv + lnv);
+            const float d = dd[1 + h][1 + e];
+            const float ad = d * diag + dd[h][1 + e] * lwv + dd[2 + h][1 + e] * lev + dd[1 + h][e] * lsv +
+                             dd[1 + h][2 + e] * lnv;  // PoissonMatrix.pde:57-61
+            rn[h][e] = r0row[e] - ad;                  // MG.pde:96
+            ro.v[e] = rn[h][e];
+            xo.v[e] = (pc.v[e] + shift) + d;           // MG.pde:95
+          }
+          store4u(pout + k, xo);
+          store4u(r + k, ro);
+          // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+          if (c4 == 0) pout[k - 1] = ((XZ ? 0.f : pin[k - 1]) + shift) + dd[1 + h][1];
+          if (c4 == CPR - 1) pout[k + 4] = ((XZ ? 0.f : pin[k + 4]) + shift) + dd[1 + h][4];
+          const bool top = (gg == 1), bot = (gg == n_);
+          if (top || bot) {
+            const int kg = (top ? 0 : (n - 1)) * m + j;
+            F4 pg;
+            if (!XZ) {
+              pg = load4u(pin + kg);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pg.v[e] = 0.f;
+            }
+            F4 xg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + dd[1 + h][1 + e];
+            store4u(pout + kg, xg);
+            if (c4 == 0) pout[kg - 1] = ((XZ ? 0.f : pin[kg - 1]) + shift) + dd[1 + h][1];
+            if (c4 == CPR - 1) pout[kg + 4] = ((XZ ? 0.f : pin[kg + 4]) + shift) + dd[1 + h][4];
+          }
+        }
+        // restrict (MG.pde:124-137): sum of the 2x2 children, reference order
+        const int ci = (g - 1) / 2 + 1, cj = (j - 1) / 2 + 1;
+        L1.r[ci * m1 + cj] = rn[0][0] + rn[0][1] + rn[1][0] + rn[1][1];
+        L1.r[ci * m1 + cj + 1] = rn[0][2] + rn[0][3] + rn[1][2] + rn[1][3];
+      }
+    if (!RESID) {  // in-place r: the next block's row a'-1 (= tile row R) must keep its ORIGINAL r (and its d)
+      lds_barrier();
+      for (int q = tid; q <= PT; q += kThreads) {  // indices 3 .. PT of the row are in use
+        lds_f *tr1 = (lds_f *)(uintptr_t)a_tr, *td1 = (lds_f *)(uintptr_t)a_td;
+        tr1[q] = tr1[R * PT + q];
+        td1[q] = td1[R * PT + q];
+      }
+    }
+  }
+#undef T_R4
+#undef T_D4
+#undef T_D1
+  __syncthreads();
+}
+
+// MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
+// coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
+// (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
+// kernels only -- and its 248 VGPRs would halve the occupancy of every kernel that calls it)
+__device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
+                                  const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
+                                  ProfT &pf, float *lds, bool fused_head = true) {
+  const int kc = P.nlev - 1;
+  int iter = 0;
+  float linf = 0.f, xsum = 0.f;
+  while (iter < P.mg_max_iters) {
+    ++iter;
+    for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
+      const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
+      if (l == 0 && iter == 1 && fused_head) {
+        mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
+      } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
+        if (l == 0)
+          mg_down_fused<false, false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
+        else  // coarse levels start from x = 0 (MG.pde:56): folded into the leg, never stored or re-read
+          mg_down_fused<false, true>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
+      } else {
+        if (l > 0) {  // x = 0 on entry (MG.pde:56); the fused legs fold this into their arithmetic
+          for (int q = threadIdx.x; q < F.n * F.m; q += kThreads) F.x[q] = 0.f;
+          __syncthreads();
+        }
+        mg_dinv(F);  // smooth(0)
+        mg_increment(F);
+        mg_restrict(F, Cc);
+      }
+      pf.mark(l == 0 ? PF_DOWN0 : (24 + l));
+      if (AFC_DIAG && l == 0 && iter == 1 && fused_head) gate_release(P);  // the streaming part of this half-step ends here
+      if (l == 0 && pf.stop == 3) return iter;
+    }
+    float rr = 0.f;
+    {
+      const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
+      for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
+      if (!(AFC_DBG_OF(P) & 4))
+        mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      else
+        mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      pf.mark(16 + kc);
+    }
+    for (int l = kc - 1; l >= 0; --l) {
+      if (l == 0 && pf.stop == 4) return iter;
+      const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
+      // the finest level's new r is only read again by a further V-cycle (or by the sequential
+      // inner product of the parity mode): normally it is not written back at all
+      const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2);
+      if (!(AFC_DBG_OF(P) & 4))
+        mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else
+        mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
+        float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
+        if (!(AFC_DBG_OF(P) & 4))
+          mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        else
+          mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+      }
+      pf.mark(l == 0 ? PF_RR : (16 + l));
+    }
+    if (P.exact_sums) rr = seq_inner(L0, sm);
+    if (rr < P.mg_tol) break;
+  }
+  if (AFC_DIAG && fused_head) gate_acquire(P);  // projection tail and the next advection follow
+  *linf_out = linf;
+  *xsum_out = xsum;
+  return iter;
+}
+
+// Tail of u.project (VectorField.pde:136-140) [+ the Heun average of BDIM.update2, BDIM.pde:95-96]:
+//   p' = p + s (s = -sum(p)/N);  u -= c * grad p';  u.setBC();  [A = (u + us)/2]
+// p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
+// shift; every reader of p (next solve's head, force, probes, field export) forms p+s itself --
+// the same float32 addition the reference's plusEq performs, so the bits are identical.
+__device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, float *lds, const float *__restrict__ p,
+                                       float shift, float *vx,
+                                       float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
+                                       float *ax, float *ay) {
+  const int n = uni(P.n), m = uni(P.m), n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
+  const int sp0 = uni(P.lev[0].sp_i0), sp1 = uni(P.lev[0].sp_i1);
+  const float cu = uni(P.lev[0].cu);
+  const float *pcx = uni(G(P.cx)), *pcy = uni(G(P.cy));
+  // a thread walks down one 4-column chunk through its group's rows, so the row above (p west of
+  // the x-faces) is the chunk it read one iteration earlier and p crosses HBM once
+  const int ngrp = kThreads / CPR, rg = threadIdx.x / CPR, c4 = threadIdx.x - rg * CPR;
+  const int rpg = (n_ + ngrp - 1) / ngrp;
+  const int g_beg = 1 + rg * rpg, g_end = (rg >= ngrp) ? 0 : ((g_beg + rpg - 1 > n_) ? n_ : g_beg + rpg - 1);
+  F4 pprev;
+  for (int g = g_beg; g <= g_end; ++g) {
+    const int k = g * m + 1 + 4 * c4;
+    const F4 pc = load4u(p + k);
+    if (g == g_beg) pprev = load4u(p + k - m);
+    const F4 pw = pprev;
+    pprev = pc;
+    const float psl = p[k - 1];
+    const F4 u4 = load4u(vx + k), v4 = load4u(vy + k);
+    F4 cx4, cy4;
+    if (g >= sp0 && g <= sp1) {  // rows that cross a body: the real coefficient arrays
+      cx4 = load4u(pcx + k);
+      cy4 = load4u(pcy + k);
+    } else {  // verified on the host: every face coefficient of the row equals cu (LevelDesc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cx4.v[e] = cy4.v[e] = cu;
+    }
+    F4 un, vn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pcs = pc.v[e] + shift, pws = pw.v[e] + shift;
+      const float pss = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift;
+      const float gx = pcs - pws, gy = pcs - pss;                // Field.pde:76-77
+      un.v[e] = u4.v[e] + cx4.v[e] * (gx * -1.f);                // VectorField.pde:138
+      vn.v[e] = v4.v[e] + cy4.v[e] * (gy * -1.f);
+    }
+    // The corrector's projected field C is only an intermediate of the Heun average: after this pass nothing reads
+    // its interior again (the next step's advection overwrites every interior cell before use; the wall columns of
+    // A are formed from registers right here).  Only rows 1 and n-2 are still read: by setBC's row copies and outflow
+    // mean and by the 4-row fix-up below.
+    if (!HEUN || g == 1 || g == n_) {
+      store4u(vx + k, un);
+      store4u(vy + k, vn);
+    }
+    if (HEUN) {  // cells on the rows setBC rewrites (0, 1, n-2, n-1) are redone below
+      const F4 b4 = load4u(ox + k), d4 = load4u(oy + k);
+      F4 a4, e4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a4.v[e] = (un.v[e] + b4.v[e]) * 0.5f;
+        e4.v[e] = (vn.v[e] + d4.v[e]) * 0.5f;
+      }
+      // wall columns: the average uses what setBC is about to put there (Field.pde:217-224):
+      // u.x mirrors the adjacent interior cell, u.y[.][0] = old u.y[.][1], u.y[.][1] = u.y[.][m-1] = 0
+      if (c4 == 0) {
+        ax[k - 1] = (un.v[0] + ox[k - 1]) * 0.5f;
+        ay[k - 1] = (vn.v[0] + oy[k - 1]) * 0.5f;
+        e4.v[0] = (0.f + d4.v[0]) * 0.5f;
+      }
+      if (c4 == CPR - 1) {
+        ax[k + 4] = (un.v[3] + ox[k + 4]) * 0.5f;
+        ay[k + 4] = (0.f + oy[k + 4]) * 0.5f;
+      }
+      store4u(ax + k, a4);
+      store4u(ay + k, e4);
+    }
+  }
+  __syncthreads();
+  setbc_vel(P, vx, vy, lds);
+  if (HEUN) {  // whole rows touched by setBC's row part or by its mean correction: 0, 1, n-2, n-1
+    for (int q = threadIdx.x; q < 4 * m; q += kThreads) {
+      const int rsel = q / m, j = q - rsel * m;
+      const int k = ((rsel < 2) ? rsel : (n - 4 + rsel)) * m + j;
+      ax[k] = (vx[k] + ox[k]) * 0.5f;
+      ay[k] = (vy[k] + oy[k]) * 0.5f;
+    }
+    __syncthreads();
+  }
+}
+
+// u.project(c, p) (VectorField.pde:130-143).  pin holds the previous pressure (+ pending shift),
+// the result is left in pout (a different buffer) with a new pending shift *shift_io.
+template <int C>
+__device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e, float *vx, float *vy,
+                                 const float *pin, float *pout,
+                                 float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
+                                 float *linf_out, ProfT &pf, float *lds) {
+  const size_t eo = e * (size_t)P.Ns;
+  Lv L0 = make_level(P, e, 0);
+  L0.x = pout;
+  L0.d = G(P.u0y) + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
+  float xsum = 0.f;
+  const int iters = mg_solve_v2(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
+  if (pf.stop >= 3 && pf.stop <= 5) return iters;
+  float psum = xsum;
+  if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
+  const float shift = uni(-1 * psum / (float)((P.n - 2) * (P.m - 2)));  // VectorField.pde:136
+  project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay);
+  *shift_io = shift;
+  pf.mark(PF_PROJECT);
+  return iters;
+}
+
+// Body.pressForce(flow.p).mult(-1) of the main cylinder (Body.pde:296-303, AFCCylinder.pde:58) by ONE WAVE: lane s
+// samples segment s (p.linear at its centre) and forms the two products pdl*nx, pdl*ny; the 40 products are then added
+// in segment order, exactly as the reference's loop accumulates them (same operands, same order, same bits as
+// eval_force), through v_readlane -- no LDS, no serial chain of dependent global loads on one thread.
+__device__ __forceinline__ void eval_force_wave(const StepParams &P, const float *p, float shift, float *fxo,
+                                                float *fyo) {
+  const int nseg = uni(P.nseg);
+  if (nseg > 64) {  // more segments than lanes: the serial form
+    eval_force(P, p, shift, fxo, fyo);
+    return;
+  }
+  const int lane = threadIdx.x & 63, m = uni(P.m);
+  float tx = 0.f, ty = 0.f;
+  if (lane < nseg) {
+    const SampleDev sd = G(P.fs)[lane];
+    const float *a = p + sd.base;
+    float val;
+    if (sd.exact) {
+      val = a[0] + shift;
+    } else {
+      val = sd.s * (sd.t * (a[m + 1] + shift) + (1 - sd.t) * (a[m] + shift)) +
+            (1 - sd.s) * (sd.t * (a[1] + shift) + (1 - sd.t) * (a[0] + shift));
+    }
+    const float pdl = val * G(P.seg_l)[lane];
+    tx = pdl * G(P.seg_nx)[lane];
+    ty = pdl * G(P.seg_ny)[lane];
+  }
+  float px = 0, py = 0;
+  for (int s = 0; s < nseg; ++s) {
+    px += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tx), s));
+    py += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ty), s));
+  }
+  *fxo = px * -1.f;
+  *fyo = py * -1.f;
+}
+
+template <int C>
+__device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
+                                   ShBcast *sh, float *lds) {
+  const size_t eo = e * (size_t)P.Ns;
+  const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
+  const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
+  float *Ax = uni(G(P.ux) + eo), *Ay = uni(G(P.uy) + eo), *Bx = uni(G(P.usx) + eo), *By = uni(G(P.usy) + eo),
+        *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo);
+  float *scratch = uni(G(P.u0x) + eo);
+  float *p0 = uni(G(P.p) + eo), *p1 = uni(G(P.d) + eo);  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
+  float l0, l1;
+  float shift = uni(*pshift);
+  ProfT pf;
+  pf.start(P);
+#if AFC_DIAG
+  pf.stop = uni((P.dbg >> 12) & 15);
+#endif
+  // half 0 = predictor, BDIM.update(): F = AdvDif(u; u0 = u); updateUP                    -> B
+  // half 1 = corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; (u+us)/2 -> C, A
+  int its[2] = {0, 0};
+  float lin[2] = {0.f, 0.f};
+#pragma nounroll
+  for (int half = 0; half < 2; ++half) {
+    const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
+    float *dx = uni(half ? Cx : Bx), *dy = uni(half ? Cy : By);
+    const float *pin = uni(half ? p1 : p0);
+    float *pout = uni(half ? p0 : p1);
+    advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+    pf.mark(PF_ADVDIF);
+    if (pf.stop == 1 + 8 * half) return;
+    forcing_band(P, dx, dy, scratch, dphi1, dphi2);
+    pf.mark(PF_FORCING);
+    setbc_vel(P, dx, dy, lds);
+    pf.mark(PF_SETBC);
+    if (pf.stop == 2 + 8 * half) return;
+    float l;
+#if AFC_DIAG
+    if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
+#endif
+    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds);
+    if (pf.stop >= 3 && pf.stop <= 6) return;
+#if AFC_DIAG
+    if (pf.stop) pf.stop += 8 * half;
+#endif
+    if (half) {
+      its[1] = it;
+      lin[1] = l;
+    } else {
+      its[0] = it;
+      lin[0] = l;
+    }
+  }
+  const int it0 = its[0], it1 = its[1];
+  l0 = lin[0];
+  l1 = lin[1];
+  *pshift = shift;
+  if (threadIdx.x < 64) {
+    float fx, fy;
+    eval_force_wave(P, p0, shift, &fx, &fy);
+  if (threadIdx.x == 0) {
+    sh->fx = fx;
+    sh->fy = fy;
+    sh->it0 = it0;
+    sh->it1 = it1;
+    sh->r0 = l0;
+    sh->r1 = l1;
+  }
+  }
+  __syncthreads();
+  pf.mark(PF_HEUN);
+}
+
+#undef AFC_DBG_OF
+}  // namespace AFC_NS
+}  // namespace afc

@@ -30,7 +30,15 @@ def test_step_kernels_keep_four_workgroups_per_cu(tmp_path):
                          for k in ("vgpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size")}
         kernels[name]["agpr_count"] = int(re.match(r"\s*(\d+)", blk).group(1))
     step = {n: v for n, v in kernels.items() if "k_agent_step" in n or "k_sim_step" in n}
-    assert len(step) == 10  # CPL = 0..4 of both kernels
+    # both kernels: CPL = 0 (reference kernels) + CPL = 1..4 x {shipped, diagnostics compiled in}
+    assert len(step) == 18
+    shipped = {n: v for n, v in step.items() if "Lb0E" in n}
+    assert len(shipped) == 8
+    for n, v in shipped.items():
+        assert v["private_segment_fixed_size"] <= 640, (n, v)  # spill budget (bytes per lane) of any step kernel
+        if "k_agent_step" in n:  # the bench / training kernel: no scratch growth against the diagnostic instantiation
+            d = step[n.replace("Lb0E", "Lb1E")]
+            assert v["private_segment_fixed_size"] <= d["private_segment_fixed_size"], (n, v, d)
     for n, v in step.items():
         assert v["vgpr_count"] + v["agpr_count"] <= 128, (n, v)
         # MI355X_MICROARCH.md: 256-thread blocks per CU <= floor(800 / (ceil(sgpr/16)*16 + 16))
