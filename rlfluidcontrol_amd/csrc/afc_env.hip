@@ -550,7 +550,20 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)
     const size_t mw_budget = (36 * 1024 + 512) / sizeof(float);
     if (fl < mw_budget) fl = mw_budget;
+    // advdif_v3's rings (4 waves x (2 x 7 + 4) rows): may take the region up to what still leaves four workgroups per
+    // CU (160 KB / 4 = 40960 B per workgroup, ~2.3 KB of it static)
+    {
+      const int m_ = sf.m - 2, cplv = (m_ + 63) / 64;
+      const size_t a3 = (size_t)afc::prod::adv3_lds_floats(cplv);
+      if (m_ == 64 * cplv && a3 > fl && a3 * sizeof(float) + 2560 <= 40960) fl = a3;
+    }
     env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * fl;
+    // advdif_v3 (one barrier-free row pipeline per wave): grids of exactly 64*CPL interior columns whose rings fit the
+    // LDS region, >= 8 rows per wave
+    P.adv_ns = 0;
+    const int m_ = sf.m - 2, n_ = sf.n - 2, cplv = (m_ + 63) / 64;
+    if (P.impl != 0 && m_ == 64 * cplv && (size_t)afc::prod::adv3_lds_floats(cplv) <= fl && (n_ + 3) / 4 >= 8)
+      P.adv_ns = afc::prod::kAdvNS;
   }
 
   int rc = AFC_OK;
@@ -631,8 +644,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   const size_t E = (size_t)env->E;
   AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
   for (AFC_AS1 float **f : fields) {
-    if (!rc) rc = dev_alloc(env, f, E * P.Ns);
-    if (!rc && hipMemset(G(*f), 0, E * P.Ns * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+    // + 64 floats: the row staging copies of advdif_v3 read up to 3 floats past the end of a row
+    if (!rc) rc = dev_alloc(env, f, E * P.Ns + 64);
+    if (!rc && hipMemset(G(*f), 0, (E * P.Ns + 64) * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   }
   if (!rc) rc = dev_alloc(env, &P.coarse, E * (size_t)P.Cs);
   if (!rc && hipMemset(G(P.coarse), 0, E * (size_t)P.Cs * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");

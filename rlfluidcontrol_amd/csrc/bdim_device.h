@@ -104,6 +104,7 @@ struct StepParams {
   int stagger_ticks;   // start delay (100 MHz ticks) per workgroup phase: de-synchronises the envs of a CU
   int impl;            // 0 = v1 reference kernels, 2 = optimised kernels
   int adv_rows;        // rows per LDS tile block in advdif_v2
+  int adv_ns;          // ring depth (rows) of advdif_v3's per-wave row pipelines; 0 = use advdif_v2
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
 };

@@ -373,6 +373,190 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
   __syncthreads();
 }
 
+// s_waitcnt vmcnt(N) with the largest even immediate N <= K (K wave-uniform): at most N of the wave's youngest
+// vector-memory operations may still be outstanding afterwards.
+__device__ __forceinline__ void wait_vm_le(int K) {
+  if (K >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if (K >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (K >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (K >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (K >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (K >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (K >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (K >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (K >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One LDS-DMA copy: lane l moves 16 bytes from sbase + voff (its own byte offset) to LDS byte address lds + 16*l.
+// Written as inline assembly so that the compiler's wait-count pass does not see an LDS write it has to drain before
+// the next LDS read: the waits are placed by hand (wait_vm_le).
+__device__ __forceinline__ void lds_dma16(const float *sbase, unsigned voff, unsigned ldsaddr) {
+  const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)ldsaddr);  // uniform by construction; pins it to an SGPR
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uni(sbase)), "s"(la) : "memory", "m0");
+}
+
+// advdif_v3: per wave a ring of kAdvNS rows per field plus two rows per base field, row pitch 64*C + 4 floats
+constexpr int kAdvNS = 7;
+__device__ __host__ __forceinline__ int adv3_lds_floats(int C) { return 4 * (2 * kAdvNS + 4) * (64 * C + 4) + 4; }
+
+// The same pass as advdif_v2 as FOUR INDEPENDENT ROW PIPELINES, one per wave, without a single workgroup barrier:
+// wave w owns a contiguous quarter of the rows and walks down it.  The rows of src it needs (i-1 .. i+2; i-2 only for
+// the west face of its first row, afterwards the east-face flux is carried down the quarter in registers) live in a
+// private ring of 7 row slots per field that the wave itself fills by the LDS-DMA path (global_load_lds_dwordx4, one
+// instruction per row and field, ceil(m/4) lanes x 16 bytes) THREE ROWS AHEAD of the row it computes; the corrector's
+// base field comes the same way, one row ahead, through a double row buffer.  The loads of the rows to come are thus
+// in flight while the current row's faces are evaluated, and a wave only ever waits for its own counted vmcnt (all
+// vector-memory operations of a wave complete in order).  Issue order of row iteration i:
+//   copies of base row i+1 | copies of src row i+5 | wait: src row i+2 | faces | wait: base row i | last add | stores
+// For grids of exactly 64*C interior columns (m = 64*C + 2: every lane owns C cells; res = 8*C) and >= 8 rows per
+// wave; the caller uses advdif_v2 otherwise.
+// The lane index, recomputed where it is used (two VALU instructions): values derived from threadIdx.x that are live
+// across the whole kernel get spilled around the register-hungry loops and every reload inside such a loop is a
+// scratch load -- a vector-memory operation whose wait drains the staging copies in flight.
+__device__ __forceinline__ unsigned lane_fresh() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+template <int C>
+__device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
+                                 const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
+                                 float *__restrict__ dy, float *lds) {
+  constexpr int m = 64 * C + 2, LQ = (m + 3) >> 2, PR = 4 * LQ, NS = kAdvNS;
+  constexpr unsigned PRB = PR * 4u;              // bytes per ring row
+  constexpr int YO = NS * PR;                    // floats from a row of the x ring to the same row of the y ring
+  constexpr int BO = 2 * NS * PR;                // floats from the x ring to the base rows: [buf][x|y]
+  const int n = uni(P.n), n_ = n - 2;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int RPW = (n_ + 3) >> 2;
+  const int i_first = 1 + wave * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
+  const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((2 * NS + 4) * PRB)));  // x ring
+  const float nu = uni(P.nu), dt = uni(P.dt);
+  const bool same = (bx == sx) && (by == sy);
+  const int nb = same ? 0 : 2;  // base-row copies per iteration
+  if (i_first <= i_last) {
+    const int r_hi = (i_last + 2 < n - 1) ? i_last + 2 : n - 1;  // last row this wave stages
+    int r_next = i_first - 2, s_next = 0;  // next row to stage and its ring slot
+#define ADV3_STAGE()                                                                   \
+  {                                                                                    \
+    const unsigned ln_ = lane_fresh();                                                 \
+    if (r_next >= 0 && r_next <= r_hi && ln_ < LQ) {                                   \
+      const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                    \
+      lds_dma16(sx, so_, ring + (unsigned)s_next * PRB);                               \
+      lds_dma16(sy, so_, ring + (unsigned)(s_next + NS) * PRB);                        \
+    }                                                                                  \
+    ++r_next;                                                                          \
+    s_next = (s_next + 1 == NS) ? 0 : s_next + 1;                                      \
+  }
+#define ADV3_BASE(row)                                                                 \
+  {                                                                                    \
+    const unsigned ln_ = lane_fresh();                                                 \
+    if (ln_ < LQ) {                                                                    \
+      const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
+      const unsigned lb_ = ring + (unsigned)(2 * NS + 2 * ((row) & 1)) * PRB;          \
+      lds_dma16(bx, so_, lb_);                                                         \
+      lds_dma16(by, so_, lb_ + PRB);                                                   \
+    }                                                                                  \
+  }
+    for (int q = 0; q < NS; ++q) ADV3_STAGE()  // rows i_first-2 .. i_first+4
+    if (nb) ADV3_BASE(i_first)
+    f2 fE2[C];
+    int s0 = 0;  // ring slot of row i-2
+    for (int i = i_first; i <= i_last; ++i) {
+      const int t = i - i_first;
+      if (nb && i < i_last) ADV3_BASE(i + 1)
+      if (t > 0) ADV3_STAGE()  // row i+5 replaces row i-2 (dead: only the first row of the quarter reads its row i-2)
+      {  // how many of the wave's youngest vector-memory operations may still be in flight once row i+2 has landed.
+        // Per iteration j, in order: nb base copies (row j+1, if j < i_last), 2 src copies (row j+5, if staged), 2
+        // stores (row j); the first iteration issues its src copies last (row i-2 is still read by its west faces).
+        int K;
+        if (t >= 3) {  // the copies of row i+2 were issued in iteration i-3: followed by its stores unless that was the first
+          K = (t > 3) ? 2 : 0;
+          for (int jj = i - 2; jj <= i; ++jj) K += ((jj < i_last) ? nb : 0) + ((jj + 5 <= r_hi) ? 2 : 0) + ((jj < i) ? 2 : 0);
+        } else {  // ... or by the prologue: rows first-2 .. first+4, then base row first; whole iterations follow
+          // (>= 8 rows per wave, so every base / src copy of the first three iterations exists)
+          K = 2 * (2 - t) + nb + nb + (t > 0 ? 2 : 0);  // rest of the prologue, this iteration's copies
+          K += t * (nb + 4);                            // earlier iterations
+        }
+        wait_vm_le(K);
+      }
+      const int j0 = 1 + C * (int)lane_fresh();
+      const unsigned lo = ring + 4u * (unsigned)j0;
+      const int s1 = (s0 + 1 >= NS) ? s0 + 1 - NS : s0 + 1, s2 = (s0 + 2 >= NS) ? s0 + 2 - NS : s0 + 2,
+                s3 = (s0 + 3 >= NS) ? s0 + 3 - NS : s0 + 3, s4 = (s0 + 4 >= NS) ? s0 + 4 - NS : s0 + 4;
+      const lds_f *r1 = (const lds_f *)(uintptr_t)(lo + (unsigned)s1 * PRB);
+      const lds_f *r2 = (const lds_f *)(uintptr_t)(lo + (unsigned)s2 * PRB);
+      const lds_f *r3 = (const lds_f *)(uintptr_t)(lo + (unsigned)s3 * PRB);
+      const lds_f *r4 = (const lds_f *)(uintptr_t)(lo + (unsigned)s4 * PRB);
+      // (row pointer, column relative to the lane's first cell) -> both components
+#define XY(r, dj) f2{(r)[(dj)], (r)[YO + (dj)]}
+      const bool rok = (i >= 2) && (i <= n - 2);  // row part of the fallback test for cells of row i
+      const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
+      float oxv[C], oyv[C];
+      f2 fEn[C], fNn[C], difv[C], ccv[C];
+      f2 fSw = {0.f, 0.f};  // lane 0: vs * 0.5*(cs + cc)
+#pragma unroll
+      for (int e = 0; e < C; ++e) {
+        const int j = j0 + e;
+        const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
+        const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
+        const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
+        ccv[e] = cc;
+        if (t == 0) {  // the quarter's first row: its west face (afterwards = the previous row's east face)
+          const lds_f *r0 = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
+          const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
+          const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});
+          fE2[e] = uo * quick_face2(XY(r0, e), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);
+        }
+        const f2 ue = 0.5f * (f2{ce.x, r3[e - 1]} + f2{cc.x, ce.x});
+        fEn[e] = ue * quick_face2(cw, cc, ce, XY(r4, e), ue, rok ? mC : 0, rokE ? mC : 0);
+        if (e == 0) {
+          const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});
+          fSw = vs * (0.5f * (cs + cc));
+        }
+        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{r1[YO + e + 1], cn.y});
+        fNn[e] = vn * quick_face2(cs, cc, cn, XY(r2, e + 2), vn, rok ? mC : 0, rok ? mCN : 0);
+        difv[e] = ce + cn - 4.f * cc + cw + cs;  // VectorField.pde:198-200
+      }
+#undef XY
+      fSw.x = lane_prev_keep(fSw.x, fNn[C - 1].x);  // south face of the lane's first cell = north face of lane-1's last
+      fSw.y = lane_prev_keep(fSw.y, fNn[C - 1].y);
+      f2 basev[C];
+      if (nb) {
+        // base row i: copied in iteration i-1 (in front of that iteration's src copies and stores, and of this
+        // iteration's copies) or by the prologue
+        wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + 2 : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
+        const lds_f *bb = (const lds_f *)(uintptr_t)(lo + (unsigned)(2 * NS + 2 * (i & 1)) * PRB);
+#pragma unroll
+        for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < C; ++e) basev[e] = ccv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < C; ++e) {
+        const f2 fW = fE2[e], fS = (e == 0) ? fSw : fNn[e > 0 ? e - 1 : 0];
+        const f2 adv = ((fW - fEn[e]) + (fS - fNn[e]));
+        const f2 o = (adv + nu * difv[e]) * dt + basev[e];  // VectorField.pde:174-175
+        oxv[e] = o.x;
+        oyv[e] = o.y;
+        fE2[e] = fEn[e];
+      }
+      const unsigned ob = 4u * (unsigned)(i * m + j0);  // byte offset of the lane's cells of row i (32-bit: SGPR base + offset)
+      __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
+      __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
+      asm volatile("" ::: "memory");
+      if (t == 0) ADV3_STAGE()  // row i+5 replaces row i-2, whose last reader was this row's west face
+      s0 = s1;
+    }
+#undef ADV3_STAGE
+#undef ADV3_BASE
+  }
+  __syncthreads();
+}
+
 // BDIM.updateUP lines 118-120 restricted to the cells where it is not the identity:
 // del != 1 or del1 != 0 (|d| < eps, plus the solid interior).  Everywhere else
 // u = 1*F - ub*0 + 0*g == F.  Results are staged (scratch) before being scattered so that every
@@ -1850,13 +2034,19 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   // half 1 = corrector, BDIM.update2(): us = u (= B); F = AdvDif(u; u0); updateUP; (u+us)/2 -> C, A
   int its[2] = {0, 0};
   float lin[2] = {0.f, 0.f};
+  // the barrier-free row pipelines where they apply (adv_ns = ring depth chosen by the host; dbg bit 10 forces the tiled form), else the tiled form
+  const int adv3_ns = uni(P.adv_ns);
+  const bool adv3_ok = adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024);
 #pragma nounroll
   for (int half = 0; half < 2; ++half) {
     const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
     float *dx = uni(half ? Cx : Bx), *dy = uni(half ? Cy : By);
     const float *pin = uni(half ? p1 : p0);
     float *pout = uni(half ? p0 : p1);
-    advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+    if (adv3_ok)
+      advdif_v3<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+    else
+      advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
     pf.mark(PF_ADVDIF);
     if (pf.stop == 1 + 8 * half) return;
     forcing_band(P, dx, dy, scratch, dphi1, dphi2);
