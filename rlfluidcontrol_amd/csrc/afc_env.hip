@@ -566,6 +566,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       P.adv_ns = afc::prod::kAdvNS;
   }
 
+  P.head_v3 = (P.impl != 0 && sf.m == 130 && ((sf.n - 2) & 7) == 0 &&
+               (size_t)afc::prod::kHeadLdsFloats * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   int rc = AFC_OK;
 #define UP(field) if (!rc) rc = dev_upload(env, &P.field, sf.field)
   UP(delx); UP(dely); UP(del1x); UP(del1y); UP(wnxx); UP(wnxy); UP(wnyx); UP(wnyy); UP(cx); UP(cy);
@@ -1044,6 +1046,13 @@ int afc_get_field(afc_env *env, int env_idx, int which, float *out) {
       src = tmp;
       break;
     }
+    // development only (tools/path_diff.py): raw work buffers of the pressure solve, valid after a launch that left the
+    // step early (dbg stop codes): 16 = second pressure buffer, 17 = finest residual, 18 = coarse scratch (first N floats)
+    case 16: src = G(P.d) + eo; break;
+    case 17: src = G(P.r) + eo; break;
+    case 18: src = G(P.coarse) + (size_t)env_idx * P.Cs; break;
+    case 19: src = G(P.usx) + eo; break;
+    case 20: src = G(P.usy) + eo; break;
     default: return fail(AFC_EINVAL, "afc_get_field: unknown field");
   }
   HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));

@@ -559,38 +559,57 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
 
 // BDIM.updateUP lines 118-120 restricted to the cells where it is not the identity:
 // del != 1 or del1 != 0 (|d| < eps, plus the solid interior).  Everywhere else
-// u = 1*F - ub*0 + 0*g == F.  Results are staged (scratch) before being scattered so that every
-// band cell sees the un-forced F of its neighbours, as the reference's whole-array expression does.
-__device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, float *scratch, float dphi1,
+// u = 1*F - ub*0 + 0*g == F.  Every band cell must see the un-forced F of its neighbours, as the reference's
+// whole-array expression does: all results are staged in LDS, one barrier, then scattered.
+// The phase moves almost no data but runs while other workgroups of the chip stream, when a dependent global-memory
+// round trip costs microseconds: a thread therefore fetches the indices of ALL its cells first (two x- and two y-cells
+// per pass), then issues every gather of every cell before the first result is needed -- two round trips per pass
+// instead of two per cell and component.
+__device__ __forceinline__ float forcing_x_cell(const StepParams &P, const float *__restrict__ fx, int k, int m,
+                                                float dphi1, float dphi2) {
+  const float del = G(P.delx)[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
+  float un = del * R - ub * (del + (-1.f));
+  const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
+  const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
+  const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
+  const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
+  const float g = 0.5f * (G(P.wnxx)[k] * (dE - dW) + G(P.wnyx)[k] * (dN - dS));
+  return un + G(P.del1x)[k] * g;
+}
+__device__ __forceinline__ float forcing_y_cell(const StepParams &P, const float *__restrict__ fy, int k, int m,
+                                                float dphi1, float dphi2) {
+  const float del = G(P.dely)[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
+  float un = del * R - ub * (del + (-1.f));
+  const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
+  const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
+  const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
+  const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
+  const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
+  return un + G(P.del1y)[k] * g;
+}
+__device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, float *stage, float dphi1,
                                     float dphi2) {
-  const int m = P.m;
-  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) {
-    const int k = G(P.band_x)[q];
-    const float del = G(P.delx)[k], R = fx[k], ub = ub_x_at(P, k, dphi1, dphi2);
-    float un = del * R - ub * (del + (-1.f));
-    const float dE = fx[k + m] - ub_x_at(P, k + m, dphi1, dphi2);
-    const float dW = fx[k - m] - ub_x_at(P, k - m, dphi1, dphi2);
-    const float dN = fx[k + 1] - ub_x_at(P, k + 1, dphi1, dphi2);
-    const float dS = fx[k - 1] - ub_x_at(P, k - 1, dphi1, dphi2);
-    const float g = 0.5f * (G(P.wnxx)[k] * (dE - dW) + G(P.wnyx)[k] * (dN - dS));
-    un = un + G(P.del1x)[k] * g;
-    scratch[q] = un;
+  // stage: LDS, nband_x + nband_y floats (the host checks that the region holds them)
+  const int m = uni(P.m), nbx = uni(P.nband_x), nby = uni(P.nband_y);
+  const int *bandx = G(P.band_x), *bandy = G(P.band_y);
+  const int tid = threadIdx.x;
+  const int nmax = nbx > nby ? nbx : nby;
+  lds_barrier();  // the region's previous user (the advection rings) is done
+  for (int base = 0; base < nmax; base += 2 * kThreads) {
+    const int q0 = base + tid, q1 = q0 + kThreads;
+    const bool x0 = q0 < nbx, x1 = q1 < nbx, y0 = q0 < nby, y1 = q1 < nby;
+    const int kx0 = x0 ? bandx[q0] : m + 1, kx1 = x1 ? bandx[q1] : m + 1;  // an idle slot reads (and ignores) cell [1][1]
+    const int ky0 = y0 ? bandy[q0] : m + 1, ky1 = y1 ? bandy[q1] : m + 1;
+    const float ux0 = forcing_x_cell(P, fx, kx0, m, dphi1, dphi2), ux1 = forcing_x_cell(P, fx, kx1, m, dphi1, dphi2);
+    const float uy0 = forcing_y_cell(P, fy, ky0, m, dphi1, dphi2), uy1 = forcing_y_cell(P, fy, ky1, m, dphi1, dphi2);
+    if (x0) stage[q0] = ux0;
+    if (x1) stage[q1] = ux1;
+    if (y0) stage[nbx + q0] = uy0;
+    if (y1) stage[nbx + q1] = uy1;
   }
-  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) {
-    const int k = G(P.band_y)[q];
-    const float del = G(P.dely)[k], R = fy[k], ub = ub_y_at(P, k, dphi1, dphi2);
-    float un = del * R - ub * (del + (-1.f));
-    const float dE = fy[k + m] - ub_y_at(P, k + m, dphi1, dphi2);
-    const float dW = fy[k - m] - ub_y_at(P, k - m, dphi1, dphi2);
-    const float dN = fy[k + 1] - ub_y_at(P, k + 1, dphi1, dphi2);
-    const float dS = fy[k - 1] - ub_y_at(P, k - 1, dphi1, dphi2);
-    const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
-    un = un + G(P.del1y)[k] * g;
-    scratch[P.nband_x + q] = un;
-  }
-  __syncthreads();
-  for (int q = threadIdx.x; q < P.nband_x; q += kThreads) fx[G(P.band_x)[q]] = scratch[q];
-  for (int q = threadIdx.x; q < P.nband_y; q += kThreads) fy[G(P.band_y)[q]] = scratch[P.nband_x + q];
+  __syncthreads();  // every gather has been consumed (the scatter below overwrites what neighbours gathered)
+  for (int q = tid; q < nbx; q += kThreads) fx[bandx[q]] = stage[q];
+  for (int q = tid; q < nby; q += kThreads) fy[bandy[q]] = stage[nbx + q];
   __syncthreads();
 }
 
@@ -619,10 +638,22 @@ __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, f
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 24;
 
-// LDS layout used by the smoother (floats, PW = m + kPad):
+// LDS layout used by the smoother (floats, PW = ring_pitch(m)):
 //   [kPad][r ring 24*PW][kPad][d ring 24*PW][kPad][zero row PW][kPad][dummy row PW]
+#ifndef AFC_KPAD
+#define AFC_KPAD 36
+#endif
+// Ring row pitch: at least m + 34 floats (the last lanes of a strip run up to column m_+35) and == 12 (mod 32): a lane
+// is one row down and one column back from its neighbour, sweep k+1 one row up and four columns back from sweep k, so
+// with pitch == 12 the 32 lanes of a half-wave hit 32 different banks (pitch 166 = m + 36 on the 256x128 grid made the
+// two sweeps of a half-wave collide on 14 of 16 banks: every LDS access of the march took twice its cycles, which is
+// what kept a second marching wave per workgroup from paying -- tools/march_bench.hip).
+__device__ __host__ __forceinline__ int ring_pitch(int m) {
+  const int lo = m + 34;
+  return lo + ((12 - lo) & 31);
+}
 __device__ __host__ __forceinline__ int gs_lds_floats(int m) {
-  return 36 /*kPad*/ + (2 * 24 /*kRing*/ + 2) * (m + 36) + 3 * 36;
+  return AFC_KPAD + (2 * 24 /*kRing*/ + 2) * ring_pitch(m) + 3 * AFC_KPAD;
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
@@ -641,13 +672,13 @@ __device__ __forceinline__ void coef_analytic(const LevelDesc &D, const DescU &d
   iv = D.invtab[3 * ((i == 1) ? 1 : ((i == n_) ? 2 : 0)) + ((j == 1) ? 1 : ((j == m_) ? 2 : 0))];
 }
 
-// Ring rows are stored with pitch PW = m + kPad; the kPad trailing floats (and a kPad front pad of
+// Ring rows are stored with pitch PW = ring_pitch(m) >= m + 34; the trailing floats (and a kPad front pad of
 // each array) only ever receive zeros.  Running pointers are never clamped: a lane that is before
 // the first / past the last column of its row reads a pad, a lane whose row lies outside the grid
 // reads the all-zero row `zrow` and writes to `dummy`.  One unsigned compare per step forces the
 // result of such a lane to 0 (which is also what its neighbours must see: ghost d = 0); its writes
 // are unconditional -- zeros into a pad or the dummy row.
-constexpr int kPad = 36;  // >= 34: the last lanes run (and write zeros) up to column m_+35
+constexpr int kPad = AFC_KPAD;  // >= 34: the last lanes run (and write zeros) up to column m_+35
 
 // The march.  EVERY sweep writes its result in place (as the sequential loops do) and reads d[i+1][j], d[i][j+1] of the
 // previous sweep from LDS; consecutive sweeps follow each other at kLag = 4 steps.  Right after steps e, e+1 of a
@@ -657,7 +688,7 @@ constexpr int kPad = 36;  // >= 34: the last lanes run (and write zeros) up to c
 constexpr int kLag = 4;
 template <bool FAST, bool ZB = true>
 __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0) {
-  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = m + kPad;
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = ring_pitch(m);
   const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
   const int i = I0 - k + c;
   const bool row_ok = (i >= 1) && (i <= n_);
@@ -1025,7 +1056,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   // rmode (finest level, chunked path): 0 = r written back; 1 = r not written back (the caller replays
   // with rmode 2 in the rare case a second V-cycle needs it); 2 = replay: same d, only r is stored
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
-  const int PW = m + kPad;
+  const int PW = ring_pitch(m);
   const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));  // diagnostics: phase marks for the level with n rows
   float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
@@ -1045,9 +1076,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
   const bool grp_on = chunked && (rg < ngrp);
   __syncthreads();
-  // zero everything once: pads and the zero row (ring interiors are overwritten by the fills)
-  // (the region is shared with the other phases' tiles, so this is redone on every call)
-  for (int q = tid; q < gs_lds_floats(m); q += kThreads) lds[q] = 0.f;
+  // Only the zero row has to hold zeros: ring interiors and the ghost columns of d are written by the fills before
+  // they are read, and what a lane reads from a pad (before the first / past the last column of its row) never
+  // reaches a result -- such a lane's value is forced to 0 by the activity test.  (The region is shared with the
+  // other phases' tiles, so this is redone on every call.)
+  for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;
   lds_barrier();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
   for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
@@ -1794,6 +1827,205 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   __syncthreads();
 }
 
+// 16-byte access at a 32-bit byte offset from a wave-uniform base: global_* with the base in SGPRs, no 64-bit lane address
+__device__ __forceinline__ F4 ld4b(const float *base, unsigned boff) {
+  F4 r;
+  __builtin_memcpy(&r, (const char *)base + boff, 16);
+  return r;
+}
+__device__ __forceinline__ float ld1b(const float *base, unsigned boff) {
+  float r;
+  __builtin_memcpy(&r, (const char *)base + boff, 4);
+  return r;
+}
+__device__ __forceinline__ void st4b(float *base, unsigned boff, const F4 &v) { __builtin_memcpy((char *)base + boff, &v, 16); }
+__device__ __forceinline__ void st1b(float *base, unsigned boff, float v) { __builtin_memcpy((char *)base + boff, &v, 4); }
+
+constexpr int kHeadNS = 8;                                       // rows in a wave's d ring
+constexpr int kHeadLdsFloats = 4 * (kHeadNS * 132 + 8) + 8;      // head_v3: four rings (m = 130: pitch 132)
+
+// The fused head (mg_down_fused<true,false>: r0 = div u - A(p+s); d = r0*inv; d.setBC; pout = (p+s) + d; r = r0 - A d;
+// r1 = restrict(r)) on grids of 128 interior columns as FOUR INDEPENDENT ROW PIPELINES without workgroup barriers:
+// wave w owns a contiguous quarter of the rows (an even number, starting on an odd row, so restriction pairs stay
+// inside a wave); lanes 0-31 / 32-63 hold the 32 four-column chunks of an odd row / the even row below it.  Per
+// iteration a wave (1) forms r0 and d of rows g+2, g+3 (one row pair ahead: d of the rows above and below a cell must
+// exist before its residual can), d into a private 8-row LDS ring with the setBC mirror in its ghost columns and
+// rows, r0 and the centre p staying in registers for one iteration; (2) finishes rows g, g+1: p, r and the
+// restricted r1 (the even row's four residuals come down to the odd row's lanes with v_permlane32_swap).  The rows
+// just outside a quarter (one above, one below) are evaluated by both neighbours.  Same expressions, same order, same
+// bits as mg_down_fused.
+__device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+                               const float *__restrict__ uy, const float *__restrict__ pin, float shift, float *lds) {
+  constexpr int m = 130, m_ = 128, CPR = 32, PT = 132, NS = kHeadNS;
+  const int n = uni(L0.n), n_ = n - 2;
+  const LevelDesc &D = *L0.desc;
+  float *pout = L0.x, *r = L0.r, *r1 = L1.r;
+  const float *lxp = L0.lx, *lyp = L0.ly, *invp = L0.inv;
+  const int m1 = uni(L1.m);
+  shift = uni(shift);
+  const float cu = uni(D.cu), iv0 = uni(D.invtab[0]);
+  const int sp_i0 = uni(D.sp_i0), sp_i1 = uni(D.sp_i1);
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int RPW = n_ >> 2;
+  const int i_first = 1 + wave * RPW, i_last = i_first + RPW - 1;
+  const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((NS * PT + 8) * 4u)));
+  // ring element (row R, column jj) at float index (R & 7)*PT + jj + 3: a lane's four columns are one aligned 16 bytes
+#define HD_D4(R, c) (*(lds_f4 *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + 4 * (c) + 4)))
+#define HD_D1(R, jj) (*(lds_f *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + (jj) + 3)))
+  F4 c_r0, c_pc;        // carried from step 1 to the next iteration's step 2: r0 and p of the lane's chunk
+  float c_psl, c_pnr;   // ... and the p values left / right of the chunk (ghost columns of the first / last chunk)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c_r0.v[e] = c_pc.v[e] = 0.f;
+  c_psl = c_pnr = 0.f;
+  // ---- step 1 on the row pair (R0, R0+1): lanes of rows outside [lo_ok, hi_ok] idle ----
+#define HD_STEP1(R0, lo_ok, hi_ok, n_r0, n_pc, n_psl, n_pnr)                                                       \
+  {                                                                                                                \
+    const unsigned ln_ = lane_fresh();                                                                             \
+    const int h_ = (int)(ln_ >> 5), c4_ = (int)(ln_ & 31u);                                                        \
+    const int R_ = (R0) + h_;                                                                                      \
+    if (R_ >= (lo_ok) && R_ <= (hi_ok)) {                                                                          \
+      const unsigned kb_ = 4u * (unsigned)(R_ * m + 1 + 4 * c4_);                                                  \
+      const bool sp_ = ((R0) + 1 >= sp_i0) && ((R0) <= sp_i1);                                                     \
+      const F4 uxc = ld4b(ux, kb_), uxe = ld4b(ux, kb_ + 4u * m), uyc = ld4b(uy, kb_);                             \
+      const float uyn = ld1b(uy, kb_ + 16u);                                                                       \
+      const F4 pc = ld4b(pin, kb_), pw = ld4b(pin, kb_ - 4u * m), pe = ld4b(pin, kb_ + 4u * m);                    \
+      const float psl = ld1b(pin, kb_ - 4u), pnr = ld1b(pin, kb_ + 16u);                                           \
+      F4 lw, le, ls, iv;                                                                                           \
+      float ln4;                                                                                                   \
+      if (sp_) {                                                                                                   \
+        lw = ld4b(lxp, kb_);                                                                                       \
+        le = ld4b(lxp, kb_ + 4u * m);                                                                              \
+        ls = ld4b(lyp, kb_);                                                                                       \
+        ln4 = ld1b(lyp, kb_ + 16u);                                                                                \
+        iv = ld4b(invp, kb_);                                                                                      \
+      } else {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = cu, iv.v[e] = iv0;             \
+        ln4 = cu;                                                                                                  \
+      }                                                                                                            \
+      f4a d4;                                                                                                      \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+        const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;                                                      \
+        const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e]; /* VectorField.pde:61-62 */                        \
+        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;          \
+        const float diag = -(lwv + lev + lsv + lnv);                                                               \
+        const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;                           \
+        const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift,                                             \
+                    pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;                                             \
+        const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv; /* PoissonMatrix.pde:57-61 */ \
+        n_r0.v[e] = div - ap;                                                                                      \
+        d4[e] = n_r0.v[e] * iv.v[e]; /* MG.pde:80 */                                                               \
+      }                                                                                                            \
+      n_pc = pc;                                                                                                   \
+      n_psl = psl;                                                                                                 \
+      n_pnr = pnr;                                                                                                 \
+      HD_D4(R_, c4_) = d4;                                                                                         \
+      if (c4_ == 0) HD_D1(R_, 0) = d4[0]; /* d.setBC(): ghosts mirror the adjacent interior cell */                \
+      if (c4_ == CPR - 1) HD_D1(R_, m_ + 1) = d4[3];                                                               \
+      if (R_ == 1 || R_ == n_) {                                                                                   \
+        const int Rg_ = (R_ == 1) ? 0 : n_ + 1;                                                                    \
+        HD_D4(Rg_, c4_) = d4;                                                                                      \
+        if (c4_ == 0) HD_D1(Rg_, 0) = d4[0];                                                                       \
+        if (c4_ == CPR - 1) HD_D1(Rg_, m_ + 1) = d4[3];                                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  const int d_hi = (i_last + 1 < n_) ? i_last + 1 : n_;  // last row whose d this wave forms itself
+  {
+    F4 t_r0, t_pc;
+    float t_a, t_b;
+    HD_STEP1(i_first - 2, (i_first - 1 > 1 ? i_first - 1 : 1), i_first - 1, t_r0, t_pc, t_a, t_b)  // the row above the quarter
+    (void)t_r0, (void)t_pc, (void)t_a, (void)t_b;
+  }
+  HD_STEP1(i_first, i_first, i_first + 1, c_r0, c_pc, c_psl, c_pnr)
+  asm volatile("" ::: "memory");
+  for (int g = i_first; g <= i_last; g += 2) {
+    F4 n_r0, n_pc;
+    float n_psl = 0.f, n_pnr = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) n_r0.v[e] = n_pc.v[e] = 0.f;
+    HD_STEP1(g + 2, g + 2, d_hi, n_r0, n_pc, n_psl, n_pnr)
+    // lanes read below what OTHER lanes of the wave have just stored: program order must survive the optimiser (for one
+    // thread the addresses are provably different); in hardware the LDS operations of a wave execute in order
+    asm volatile("" ::: "memory");
+    {  // ---- step 2: rows g (lanes 0-31), g+1 (lanes 32-63) ----
+      const unsigned ln = lane_fresh();
+      const int h = (int)(ln >> 5), c4 = (int)(ln & 31u);
+      const int G = g + h, j = 1 + 4 * c4;
+      const unsigned kb = 4u * (unsigned)(G * m + j);
+      const bool sp = (g + 1 >= sp_i0) && (g <= sp_i1);
+      F4 lw, le, ls;
+      float ln4;
+      if (sp) {
+        lw = ld4b(lxp, kb);
+        le = ld4b(lxp, kb + 4u * m);
+        ls = ld4b(lyp, kb);
+        ln4 = ld1b(lyp, kb + 16u);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = cu;
+        ln4 = cu;
+      }
+      const f4a dc = HD_D4(G, c4), dw = HD_D4(G - 1, c4), de = HD_D4(G + 1, c4);
+      const float dl = HD_D1(G, j - 1), dr = HD_D1(G, j + 4);
+      const float d6[6] = {dl, dc[0], dc[1], dc[2], dc[3], dr};
+      F4 xo, ro;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lwv + lev + lsv + lnv);
+        const float d = d6[1 + e];
+        const float ad = d * diag + dw[e] * lwv + de[e] * lev + d6[e] * lsv + d6[2 + e] * lnv;  // PoissonMatrix.pde:57-61
+        ro.v[e] = c_r0.v[e] - ad;                                                              // MG.pde:96
+        xo.v[e] = (c_pc.v[e] + shift) + d;                                                     // MG.pde:95
+      }
+      st4b(pout, kb, xo);
+      st4b(r, kb, ro);
+      // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+      if (c4 == 0) st1b(pout, kb - 4u, (c_psl + shift) + d6[1]);
+      if (c4 == CPR - 1) st1b(pout, kb + 16u, (c_pnr + shift) + d6[4]);
+      if (G == 1 || G == n_) {
+        const unsigned kg = 4u * (unsigned)(((G == 1) ? 0 : (n - 1)) * m + j);
+        const F4 pg = ld4b(pin, kg);
+        F4 xg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + d6[1 + e];
+        st4b(pout, kg, xg);
+        if (c4 == 0) st1b(pout, kg - 4u, (ld1b(pin, kg - 4u) + shift) + d6[1]);
+        if (c4 == CPR - 1) st1b(pout, kg + 16u, (ld1b(pin, kg + 16u) + shift) + d6[4]);
+      }
+      // restrict (MG.pde:124-137): sum of the 2x2 children in the reference order; the even row's residuals come down
+      // from lanes 32-63
+      float up[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b; afterwards b's lanes 0-31 hold what a's lanes
+        // 32-63 held.  (Written out: with the builtin on two copies of one value and only the second result used, hipcc
+        // 7.2 hands back the first -- the lane's own value; s_nop 1 = the two wait states between a VALU write of an
+        // operand and the swap.)
+        float a_ = ro.v[e], b_ = ro.v[e];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+        up[e] = b_;
+      }
+      if (h == 0) {
+        const int ci = (g - 1) / 2 + 1, cj = 2 * c4 + 1;
+        float two[2];
+        two[0] = ro.v[0] + ro.v[1] + up[0] + up[1];
+        two[1] = ro.v[2] + ro.v[3] + up[2] + up[3];
+        __builtin_memcpy((char *)r1 + 4u * (unsigned)(ci * m1 + cj), two, 8);
+      }
+    }
+    asm volatile("" ::: "memory");
+    c_r0 = n_r0;
+    c_pc = n_pc;
+    c_psl = n_psl;
+    c_pnr = n_pnr;
+  }
+#undef HD_STEP1
+#undef HD_D4
+#undef HD_D1
+  __syncthreads();
+}
+
 // MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
 // (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
@@ -1809,7 +2041,10 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
     for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
       const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
       if (l == 0 && iter == 1 && fused_head) {
-        mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
+        if (F.m == 130 && ((F.n - 2) & 7) == 0 && uni(P.head_v3) && !(AFC_DBG_OF(P) & 2048))
+          head_v3(P, L0, Cc, ux, uy, pin, shift, lds);
+        else
+          mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
       } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
         if (l == 0)
           mg_down_fused<false, false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
@@ -2021,7 +2256,6 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
   const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
   float *Ax = uni(G(P.ux) + eo), *Ay = uni(G(P.uy) + eo), *Bx = uni(G(P.usx) + eo), *By = uni(G(P.usy) + eo),
         *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo);
-  float *scratch = uni(G(P.u0x) + eo);
   float *p0 = uni(G(P.p) + eo), *p1 = uni(G(P.d) + eo);  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
   float shift = uni(*pshift);
@@ -2049,7 +2283,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
       advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
     pf.mark(PF_ADVDIF);
     if (pf.stop == 1 + 8 * half) return;
-    forcing_band(P, dx, dy, scratch, dphi1, dphi2);
+    forcing_band(P, dx, dy, lds, dphi1, dphi2);
     pf.mark(PF_FORCING);
     setbc_vel(P, dx, dy, lds);
     pf.mark(PF_SETBC);

@@ -6,6 +6,10 @@
 #include <cstdlib>
 #include <vector>
 using namespace afc;
+using namespace afc::prod;
+#ifndef NW
+#define NW 1  // marching waves per workgroup (all on the same rings: timing only)
+#endif
 #ifndef MARCH_CALL
 #define MARCH_CALL                                           \
   if (D.zero_bnd)                                            \
@@ -16,7 +20,7 @@ using namespace afc;
 __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstrips, float *out, long long *ticks,
                                              const float *coef, int generic) {
   extern __shared__ float lds[];
-  const int PW = m + kPad;
+  const int PW = ring_pitch(m);
   float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
   for (int q = threadIdx.x; q < gs_lds_floats(m); q += blockDim.x) lds[q] = 0.f;
   __syncthreads();
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256, 4) void k(LevelDesc D, int n, int m, int nstri
   L.r = L.x = L.d = nullptr;
   L.desc = &D;
   long long t0 = 0;
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 64 * NW) {
     t0 = wall_clock64();
     for (int s = 0; s < nstrips; ++s) {
       const int I0 = 17 + 16 * (s % 13);  // interior strips
