@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/sec of the batched BDIM cylinder-wake environment on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--res R] [--reynolds RE]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--res R] [--reynolds RE] [--gs-mode 0|1]
 
 A "step" is one AGENT step of the whole batch: 16 x AFCCylinder.update2 per env (clientCFD.pde:12,
 35-56) in ONE kernel launch, then (N>1) the RCCL all-gather of (obs, reward, done).  Workload at
@@ -25,6 +25,73 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CELL_STEP = 176.0  # 44 fp32 field passes per sim-step
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+# committed start states: (res, Re) -> file
+DEFAULT_INIT = {(16, 100): os.path.join(GOLDEN, "wake_res16_re100.npz"),
+                (32, 400): os.path.join(GOLDEN, "wake_res32_re400.npz"),
+                (24, 500): os.path.join(GOLDEN, "init_bdim_res24.npz")}
+# BASELINE.json workloads by (res, Re, envs per GPU)
+WORKLOADS = {(16, 100, 1024): "BASELINE.json configs[1]",
+             (32, 400, 1024): "BASELINE.json configs[3]",
+             (24, 500, 1024): "reference-native 384x192 Re500 (init.bdim)"}
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: ties a committed PMC traffic figure to the code it was
+    measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rlfluidcontrol_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class _StubEnv:
+    """--dry-run-cpu: stands in for AFCEnv on a box without a GPU (torch CPU tensors, a fixed sleep per agent step)"""
+    n, m = 258, 130
+
+    def __init__(self, num_envs, rank):
+        import torch
+        self.E, self.rank, self.torch = num_envs, rank, torch
+        self.hist = np.zeros(8, np.int64)
+
+    def step(self, action, obs, rew, done, nst):
+        time.sleep(0.002 * (1 + self.rank))  # ranks differ: the slowest one defines the step
+        obs.copy_(action * 0.5 + self.rank)
+        rew.copy_(-obs[:, 1])
+        done.zero_()
+        nst.fill_(16)
+        self.hist[0] += 2 * 16 * self.E
+
+    def diverged(self):
+        return np.zeros(self.E, np.uint8)
+
+    def solver_stats(self):
+        return np.ones((self.E, 2), np.int32), np.zeros((self.E, 2), np.float32)
+
+    def mg_histogram(self, clear=False):
+        h = self.hist.copy()
+        if clear:
+            self.hist[:] = 0
+        return h
+
+    def close(self):
+        pass
+
+
+class _CpuEvent:
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: HBM3E spec peak; the achievable copy rate of the box is measured in the run
 
 
@@ -106,7 +173,7 @@ def _spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=64, help="timed agent steps per pass (SURVEY 8(d): >= 64)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--res", type=int, default=16, help="resolution: grid = 16*res x 8*res")
@@ -114,10 +181,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-us", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0, help="experiment switches (development only)")
-    ap.add_argument("--init", default=os.path.join(ROOT, "tests", "golden", "wake_res16_re100.npz"),
-                    help="developed-wake state to start from (falls back to the free stream)")
+    ap.add_argument("--init", default=None,
+                    help="state (.npz with u, v, p) to start from; default: the committed state of the workload "
+                         "(developed wake for 256x128 Re 100 and 512x256 Re 400, the reference's init.bdim for 384x192 "
+                         "Re 500), else the free stream")
+    ap.add_argument("--gs-mode", type=int, default=0,
+                    help="0 = the reference's lexicographic Gauss-Seidel (headline); 1 = red-black perf mode (separate line)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="exercise the launch / rendezvous / gather / reporting path on CPU (gloo) with a stub in place "
+                         "of the HIP env: for tests of the N>1 path on boxes without GPUs; the numbers mean nothing")
     ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps agent steps; the median is reported")
     args = ap.parse_args()
+    if args.init is None:
+        args.init = DEFAULT_INIT.get((args.res, args.reynolds))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become one (children are started before any GPU call in this process)
@@ -133,28 +209,48 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.res, args.reynolds, args.init)
     import torch
-    if not torch.cuda.is_available():
+    dry = args.dry_run_cpu
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=dev)
 
-    from rlfluidcontrol_amd import build, env as envmod
-    build.build()
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def new_event():
+        return _CpuEvent() if dry else torch.cuda.Event(enable_timing=True)
+
     E = args.envs
-    g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank,
-                      stagger_us=args.stagger_us, dbg=args.dbg)
     init_used = "free stream"
-    if args.init and os.path.exists(args.init):
-        z = np.load(args.init)
-        if z["u"].shape == (g.n, g.m):
-            g.set_reset_state(z["u"], z["v"], z["p"])
-            init_used = os.path.basename(args.init)
-    stream = torch.cuda.current_stream()
-    g.use_device_io(stream.cuda_stream)
+    if dry:
+        g = _StubEnv(E, rank)
+        stream = None
+        eff_dbg = 0
+    else:
+        from rlfluidcontrol_amd import build, env as envmod
+        build.build()
+        g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank,
+                          stagger_us=args.stagger_us, dbg=args.dbg, gs_mode=args.gs_mode)
+        eff_dbg = int(g.cfg.reserved[0])  # includes AFC_DBG from the environment: recorded in the line
+        if args.init and os.path.exists(args.init):
+            z = np.load(args.init)
+            if z["u"].shape == (g.n, g.m):
+                g.set_reset_state(z["u"], z["v"], z["p"])
+                init_used = os.path.basename(args.init)
+        stream = torch.cuda.current_stream()
+        g.use_device_io(stream.cuda_stream)
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -170,7 +266,10 @@ def main():
         action.uniform_(-1.0, 1.0, generator=gen)
         if ev is not None:
             ev[0].record(stream)
-        g.agent_step_device(action.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), nst.data_ptr())
+        if dry:
+            g.step(action, obs, rew, done, nst)
+        else:
+            g.agent_step_device(action.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), nst.data_ptr())
         if ev is not None:
             ev[1].record(stream)
         if world > 1:  # the only collective on the path: (obs, reward, done) to every rank
@@ -182,18 +281,19 @@ def main():
             dist.all_gather_into_tensor(gathered, packed)
             if gev is not None:
                 gev[1].record(stream)
-        g.reset(done.data_ptr())  # restart finished episodes (mask on device)
+        if not dry:
+            g.reset(done.data_ptr())  # restart finished episodes (mask on device)
 
     warm_sum = torch.zeros((), dtype=torch.int64, device=dev)
     for _ in range(args.warmup):
         agent_step()
         warm_sum += nst.sum()  # same torch ops as the timed loop (their first call loads a code object)
-    torch.cuda.synchronize()
+    sync()
     g.mg_histogram(clear=True)
 
     # device-to-device copy ceiling of THIS box, measured in the same run (1 GiB float4 copy, read + write bytes)
     copy_bw = None
-    if rank == 0:
+    if rank == 0 and not dry:
         nb = 1 << 30
         a = torch.empty(nb // 4, dtype=torch.float32, device=dev).normal_()
         b = torch.empty_like(a)
@@ -213,18 +313,18 @@ def main():
     for _rep in range(max(1, args.repeats)):
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        gevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        sync()
+        evs = [(new_event(), new_event()) for _ in range(args.steps)]
+        gevs = [(new_event(), new_event()) for _ in range(args.steps)]
         sim_steps = torch.zeros((), dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
         for k in range(args.steps):
             agent_step(evs[k], gevs[k] if world > 1 else None)
             sim_steps += nst.sum()
-        torch.cuda.synchronize()
+        sync()
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
         tm = torch.tensor([el], device=dev, dtype=torch.float64)
         ts = torch.tensor([float(sim_steps.item())], device=dev, dtype=torch.float64)
@@ -251,7 +351,12 @@ def main():
         sim_per_launch = my_sim / args.steps
         avg_kern_s = float(np.mean(kern_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_CELL_STEP * cells * sim_per_launch / avg_kern_s
-        std = (args.res, args.reynolds, E) == (16, 100, 1024)
+        std = (args.res, args.reynolds, E) == (16, 100, 1024) and args.gs_mode == 0
+        workload = WORKLOADS.get((args.res, args.reynolds, E), "custom")
+        if args.gs_mode:
+            workload += " -- PERF MODE smoother (red-black Gauss-Seidel: not the reference's iterates, see DESIGN)"
+        if dry:
+            workload = "dry run on CPU (stub env): launch / gather / reporting path only"
         line = {
             "metric": "env-steps/sec, 256x128 Re=100 cylinder, 1024 envs @ 1/2/4/8 GPUs" if std else
                       "env-steps/sec, %dx%d Re=%d cylinder, %d envs/GPU" % (16 * args.res, 8 * args.res, args.reynolds, E),
@@ -261,10 +366,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (init: %s; actions U(-1,1)^2 per env per agent step, Philox seed 1234+rank)" % init_used,
-            "config": {"workload": "BASELINE.json configs[1]" if std else "custom",
+            "config": {"workload": workload,
                        "envs_per_gpu": E, "grid": "%dx%d" % (16 * args.res, 8 * args.res), "reynolds": args.reynolds,
                        "sim_steps_per_agent_step": 16, "parallelism": "env-sharded x%d" % world,
-                       "gs_order": "lexicographic (reference order)", "mg_iters_last": [int(it[:, 0].max()), int(it[:, 1].max())],
+                       "gs_order": "red-black (perf mode)" if args.gs_mode else "lexicographic (reference order)",
+                       "dbg": eff_dbg, "kernel_src_sha16": kernel_source_hash(), "mg_iters_last": [int(it[:, 0].max()), int(it[:, 1].max())],
                        "mg_iters_histogram": {("%d" % (k + 1)) if k < 7 else ">=8": int(hist[k]) for k in range(8) if hist[k]}},
             "timing": {"repeats": len(passes), "reported": "median pass", "ms_per_step_all_passes":
                        [round(1e3 * q[0] / args.steps, 3) for q in passes], "ms_per_step_per_rank": per_rank_ms,
@@ -279,24 +385,29 @@ def main():
                          "copy_ceiling_measured_GBs": round(copy_bw / 1e9, 1) if copy_bw else None,
                          "frac_of_measured_copy_ceiling": round(achieved / copy_bw, 5) if copy_bw else None},
         }
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be
-        # driven from inside this process); only valid for the exact workload they were taken on
-        for tag in ("r2", "r1"):
-            tpath = os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)
-            if os.path.exists(tpath) and std:
-                try:
-                    tj = json.load(open(tpath))
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be driven from inside
+        # this process): attached only for the exact workload AND the exact kernel sources they were taken on
+        tpath = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
+        if os.path.exists(tpath) and std and not dry:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("kernel_src_sha16") == kernel_source_hash():
                     line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tag
-                    break
-                except Exception:
-                    pass
+                    line["roofline"]["traffic_source"] = "profiles/r3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources)"
+                else:
+                    line["roofline"]["traffic_source"] = "none: profiles/r3_hbm_traffic.json was measured on other kernel sources (%s)" % tj.get("kernel_src_sha16")
+            except Exception:
+                pass
+        if (args.res, args.reynolds) == (32, 400):
+            line["roofline"]["note"] = ("176 B per cell and sim-step is the contract figure for every grid; at 512x256 "
+                                        "level 1 no longer fits on chip and streams (SURVEY 8(d): ~185 B per cell)")
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
     g.close()
     if dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

@@ -96,7 +96,13 @@ typedef struct afc_config {
                            256 cells in y (y_lengths*resolution <= 256: four columns per lane); afc_create
                            rejects taller grids with AFC_EINVAL -- create those with impl = 0 */
   int32_t stagger_us;   /* start offset between the (up to 4) envs sharing a CU, microseconds (0 = none) */
-  int32_t reserved[4];
+  int32_t reserved[1];  /* [0]: development switches (StepParams.dbg); 0 in production */
+  int32_t gs_mode;      /* MG.smooth (MG.pde:79-92): 0 (default) = the reference's in-place lexicographic Gauss-Seidel,
+                           iterate for iterate (every parity test runs in this mode; the headline benchmark too);
+                           1 = PERF MODE: red-black Gauss-Seidel (4 sweeps = 8 half-sweeps per smooth), a different
+                           but equally convergent smoother -- results agree with the reference to the tolerance stated
+                           in DESIGN.md and tests/test_gpu_perfmode.py, not bit for bit */
+  int32_t reserved2[2];
 } afc_config;
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */

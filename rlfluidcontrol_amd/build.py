@@ -13,7 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libafc_env.so")
-SOURCES = ["afc_env.hip", "geometry.cpp"]
+# translation units, compiled in parallel: the C ABI + small kernels, the three instantiations of the step kernels
+# (shipped / diagnostics compiled in / perf mode: step_kernels.h), the host geometry
+SOURCES = ["afc_env.hip", "step_prod.hip", "step_diag.hip", "step_perf.hip", "geometry.cpp"]
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
@@ -23,7 +25,7 @@ def _deps():
 # -fno-slp-vectorize: left to itself the SLP vectoriser pairs scalar float operations into v_pk_*_f32 and pays for it
 # in register moves (every phase here is bound by VALU issue); packed arithmetic is written out where it pays
 # (the QUICK faces of advdif_v2).  Measured +2 % on the whole step.
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
@@ -46,10 +48,29 @@ def build(force=False, verbose=False):
             if force or needs_build():
                 hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
                 tmp = LIB + ".tmp.%d" % os.getpid()
-                cmd = [hipcc] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-                if verbose:
-                    print(" ".join(cmd))
-                subprocess.check_call(cmd)
+                objdir = os.path.join(HERE, "build")
+                os.makedirs(objdir, exist_ok=True)
+                jobs = []
+                for src in SOURCES:
+                    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".%d.o" % os.getpid())
+                    cmd = [hipcc] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, src)]
+                    if verbose:
+                        print(" ".join(cmd))
+                    jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                failed = []
+                for obj, cmd, pr in jobs:
+                    out = pr.communicate()[0].decode(errors="replace")
+                    if pr.returncode != 0:
+                        failed.append((cmd, out))
+                    elif verbose and out.strip():
+                        print(out)
+                if failed:
+                    for cmd, out in failed:
+                        sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
+                    raise subprocess.CalledProcessError(1, failed[0][0])
+                subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + [j[0] for j in jobs])
+                for obj, _, _ in jobs:
+                    os.remove(obj)
                 os.replace(tmp, LIB)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)

@@ -15,7 +15,9 @@
 
 #include "../../include/afc_env.h"
 #include "bdim_device.h"
+#define AFC_ONLY_MODE 0  // host-side helpers of the optimised phases only (LDS sizes)
 #include "bdim_v2.h"
+#include "step_launch.h"
 #include "geometry.h"
 
 namespace {
@@ -37,155 +39,7 @@ using afc::G;
 using afc::kThreads;
 using afc::StepParams;
 
-// ---------------- kernels ----------------
-// CPL = columns per lane of the optimised kernels (grid height m-2 <= 64*CPL); CPL = 0 selects the
-// straightforward reference kernels.  One instantiation per CPL keeps each kernel's register
-// budget at 4 workgroups (16 waves) per CU.
-// DIAG selects the instantiation of the optimised phases with the diagnostics compiled in (bdim_v2.h); the shipped
-// kernels are <CPL, false>.
-template <int CPL, bool DIAG>
-__device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
-                                              double *sm, afc::ShBcast *sh, float *lds) {
-  if constexpr (CPL == 0)
-    afc::sim_step(P, e, a, b, sm, sh);
-  else if constexpr (DIAG)
-    afc::diag::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
-  else
-    afc::prod::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
-}
-
-template <int CPL, bool DIAG>
-__global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams *__restrict__ Pp,
-                                                               const float *__restrict__ xi_m,
-                                                               float *__restrict__ force) {
-  const StepParams &P = *Pp;  // parameters live in device memory: phase functions take them by reference
-  __shared__ double sm[afc::kThreads];
-  __shared__ afc::ShBcast sh;
-  extern __shared__ float lds_dyn[];
-  const size_t e = blockIdx.x;
-  const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
-  float pshift = G(P.sc)[e].p_shift;
-  if (DIAG) afc::gate_init(P);
-  __syncthreads();
-  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
-  step_dispatch<CPL, DIAG>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
-  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P, true);
-  if (threadIdx.x == 0) {
-    EnvScalars &s = G(P.sc)[e];
-    s.p_shift = pshift;
-    s.xi1_m = a;
-    s.xi2_m = b;
-    s.t += P.dt / P.resolution;  // AFCCylinder.pde:56
-    s.force_x = sh.fx;
-    s.force_y = sh.fy;
-    s.iters[0] = sh.it0;
-    s.iters[1] = sh.it1;
-    s.resid[0] = sh.r0;
-    s.resid[1] = sh.r1;
-    s.sim_steps += 1;
-    s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;  // clamped: diagnostic launches that leave the step early
-    s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;  // do not fill sh
-    if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
-    if (force) {
-      force[2 * e] = sh.fx;
-      force[2 * e + 1] = sh.fy;
-    }
-  }
-}
-
-// The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
-template <int CPL, bool DIAG>
-__global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParams *__restrict__ Pp,
-                                                                 const float *__restrict__ action,
-                                                                 float *__restrict__ obs, float *__restrict__ reward,
-                                                                 uint8_t *__restrict__ done, int *__restrict__ nsteps,
-                                                                 int max_steps) {
-  const StepParams &P = *Pp;
-  __shared__ double sm[afc::kThreads];
-  __shared__ afc::ShBcast sh;
-  extern __shared__ float lds_dyn[];
-  const size_t e = blockIdx.x;
-  if (DIAG && P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
-    const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
-    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
-  }
-  // the env's episode scalars live in LDS for the whole launch (thread 0 does the bookkeeping of
-  // clientCFD.pde:35-56, everybody reads what the control flow needs): no per-thread register copies
-  __shared__ EnvScalars s;
-  __shared__ int s_stop;
-  const float a1 = action[2 * e], a2 = action[2 * e + 1];
-  if (threadIdx.x == 0) {
-    s = G(P.sc)[e];
-    s.xi1 = a1;  // clientCFD.pde:51-54
-    s.xi2 = a2;
-    s.xi1_m = P.act_scale * s.xi1;
-    s.xi2_m = P.act_scale * s.xi2;
-    s.window_done = 0;
-    s_stop = 0;
-  }
-  if (DIAG) afc::gate_init(P);
-  __syncthreads();
-  if (DIAG && CPL != 0) afc::gate_acquire(P);
-  const float xi1_m = afc::prod::uni(s.xi1_m), xi2_m = afc::prod::uni(s.xi2_m);
-  float pshift = s.p_shift;
-  int steps = 0;
-  long long dbg_t0 = 0;
-  while (steps < max_steps) {
-    if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
-    if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
-    step_dispatch<CPL, DIAG>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
-    ++steps;
-    if (threadIdx.x == 0) {
-      s.t += P.dt / P.resolution;
-      s.force_x = sh.fx;
-      s.force_y = sh.fy;
-      s.iters[0] = sh.it0;
-      s.iters[1] = sh.it1;
-      s.resid[0] = sh.r0;
-      s.resid[1] = sh.r1;
-      s.sim_steps += 1;
-      s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;
-      s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;
-      if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
-      if (s.t > P.init_time) {  // clientCFD.pde:39-47
-        s.callLearn--;
-        s.Cd += sh.fx;
-        s.Cl += sh.fy;
-        if (s.callLearn <= 0) {
-          s.callLearn = P.substeps;
-          s.Cd = s.Cd / s.callLearn * 2 / P.resolution;
-          s.Cl = s.Cl / s.callLearn * 2 / P.resolution;
-          s.obs_cl = s.Cl;
-          s.obs_cd = s.Cd;
-          if (!P.carry_quirk) {
-            s.Cd = 0.f;
-            s.Cl = 0.f;
-          }
-          s.window_done = 1;
-          s_stop = 1;
-        }
-      }
-    }
-    __syncthreads();
-    if (s_stop) break;
-  }
-  if (DIAG && CPL != 0) afc::gate_release(P, true);
-  if (threadIdx.x == 0) {
-    s.p_shift = pshift;
-    G(P.sc)[e] = s;
-    obs[2 * e] = s.obs_cl;  // wire order is Cl then Cd (clientCFD.pde:120)
-    obs[2 * e + 1] = s.obs_cd;
-    const float aa1 = afc::jabs(a1), aa2 = afc::jabs(a2);
-    reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
-    done[e] = (!(s.t < P.end_time)) ? 1 : 0;
-    if (nsteps) nsteps[e] = steps;
-    if (DIAG && (P.dbg & 8)) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
-      obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
-      obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
-    }
-  }
-}
-
+// ---------------- kernels (the step kernels live in step_kernels.h: three translation units) ----------------
 __global__ void k_reset(StepParams P, const uint8_t *__restrict__ mask, const float *__restrict__ ru,
                         const float *__restrict__ rv, const float *__restrict__ rp, int keep_window) {
   const size_t e = blockIdx.x;
@@ -270,81 +124,11 @@ __global__ void k_cfl(StepParams P, float *__restrict__ out) {
   if (threadIdx.x == 0) out[e] = 1.f / (sm[0] + 3.f * P.nu);
 }
 
-// unit-level operators on env 0 (same device functions as the step)
-template <bool DIAG>
-__global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
-  extern __shared__ float lds_dyn[];
-  if (P.impl == 0) {
-    afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
-    return;
-  }
-  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {  // F starts as a copy of u (VectorField.pde:171)
-    G(P.fx)[k] = G(P.ux)[k];
-    G(P.fy)[k] = G(P.uy)[k];
-  }
-  __syncthreads();
-  const int m_ = P.m - 2;
-#define ADV(c)                                                                                          \
-  do {                                                                                                  \
-    if constexpr (DIAG)                                                                                 \
-      afc::diag::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);      \
-    else                                                                                                \
-      afc::prod::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn);      \
-  } while (0)
-  if (m_ <= 64) ADV(1);
-  else if (m_ <= 128) ADV(2);
-  else if (m_ <= 192) ADV(3);
-  else ADV(4);
-#undef ADV
-}
+// unit-level operators on env 0 (same device functions as the step; advdif / mg: step_kernels.h)
 __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   __shared__ double sm[afc::kThreads];
   afc::phase_setbc_u(P, 0, sm);
 }
-template <bool DIAG>
-__global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iters, float *linf) {
-  __shared__ double sm[afc::kThreads];
-  // b is staged in fx; x in p.  r = b - A x  (MG.pde:51)
-  const afc::Lv L0 = afc::make_level(P, 0, 0);
-  const int n = P.n, m = P.m;
-  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {
-    const int i = k / m, j = k - i * m;
-    float rv = G(P.fx)[k];  // b.minus(A.times(x)): ghosts of A x are 0 -> r ghost = b ghost
-    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
-      const float lw = L0.lx[k], le = L0.lx[k + m], ls = L0.ly[k], ln = L0.ly[k + 1];
-      const float diag = -(lw + le + ls + ln);
-      const float *p = G(P.p);
-      rv = G(P.fx)[k] - (p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln);
-    }
-    G(P.r)[k] = rv;
-  }
-  __syncthreads();
-  float l;
-  extern __shared__ float lds_dyn[];
-  int it;
-  if (P.impl == 0) {
-    afc::Prof pf;
-    pf.start(P);
-    it = afc::mg_solve(P, 0, sm, &l, pf);
-  } else {
-    afc::Lv L0v = afc::make_level(P, 0, 0);
-    L0v.d = G(P.u0y);
-    float xs;
-    if constexpr (DIAG) {
-      afc::diag::ProfT pf;
-      pf.start(P);
-      it = afc::diag::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
-    } else {
-      afc::prod::ProfT pf;
-      it = afc::prod::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
-    }
-  }
-  if (threadIdx.x == 0) {
-    *iters = it;
-    *linf = l;
-  }
-}
-
 }  // namespace
 
 // ---------------- host side ----------------
@@ -441,6 +225,12 @@ bool need_diag(const afc_env *env) {
   return P.dbg != 0 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
 }
 
+// 0 = shipped kernels, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; diagnostics are not available in it)
+int launch_mode(const afc_env *env) {
+  if (env->P.gs_mode == 1) return 2;
+  return need_diag(env) ? 1 : 0;
+}
+
 int launch_check(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AFC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -484,6 +274,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (cfg->num_envs < 1) return fail(AFC_EINVAL, "afc_create: num_envs must be >= 1");
   if (cfg->substeps < 1 || cfg->mg_max_iters < 1) return fail(AFC_EINVAL, "afc_create: substeps/mg_max_iters");
   if (cfg->impl != 0 && cfg->impl != 2) return fail(AFC_EINVAL, "afc_create: impl must be 0 (reference kernels) or 2");
+  if (cfg->gs_mode != 0 && cfg->gs_mode != 1) return fail(AFC_EINVAL, "afc_create: gs_mode must be 0 (lexicographic) or 1 (red-black)");
+  if (cfg->gs_mode == 1 && cfg->impl != 2) return fail(AFC_EINVAL, "afc_create: gs_mode 1 needs impl 2");
+  if (cfg->gs_mode == 1 && cfg->exact_sums) return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) and exact_sums (parity mode) exclude each other");
   if (cfg->y_lengths * cfg->resolution > 256 && cfg->impl != 0) return fail(AFC_EINVAL, "afc_create: impl 2 supports up to 256 cells in y");
   int ndev = 0;
   hipError_t he = hipGetDeviceCount(&ndev);
@@ -537,6 +330,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.carry_quirk = cfg->carry_quirk;
   P.exact_sums = cfg->exact_sums;
   P.impl = cfg->impl;
+  P.gs_mode = cfg->gs_mode;
   P.dbg = cfg->reserved[0];
   P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
   P.stagger_shift = (cfg->stagger_us >> 20) & 63;  // experimental: bits 0-3 = block-index shift, bits 4-5 = phases-2
@@ -674,12 +468,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     hipDeviceProp_t prop;
     bool ok = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess);
     if (ok) cus = prop.multiProcessorCount;
-    switch (env->cpl) {
-#define OCC(c) case c: ok = ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_agent_step<c, true>, kThreads, env->lds_bytes) == hipSuccess); break
-      OCC(1); OCC(2); OCC(3); OCC(4);
-#undef OCC
-      default: ok = false;
-    }
+    ok = ok && env->cpl >= 1 && afc::occupancy_agent_step_diag(env->cpl, env->lds_bytes, &per_cu) == 0;
     if (!ok || (long long)per_cu * cus < (long long)E || P.gate_n[0] == 0 || P.gate_n[1] == 0) P.gate_limit = 0;
   }
   if (!rc) rc = dev_alloc(env, &env->d_stamps, (size_t)32);
@@ -921,12 +710,10 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
   }
   if (int rcp = sync_params(env)) return rcp;
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
-  const bool dg = need_diag(env);
-  switch (env->cpl) {
-#define LAUNCH(c) case c: if (dg) hipLaunchKernelGGL((k_sim_step<c, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); else hipLaunchKernelGGL((k_sim_step<c, false>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break
-    case 0: hipLaunchKernelGGL((k_sim_step<0, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dxi, dforce); break;
-    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
-#undef LAUNCH
+  switch (env->cpl == 0 ? 1 : launch_mode(env)) {  // the reference kernels (cpl 0) live in the diagnostic unit
+    case 1: afc::launch_sim_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce); break;
+    case 2: afc::launch_sim_step_perf(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce); break;
+    default: afc::launch_sim_step_prod(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce);
   }
   int rc = launch_check("k_sim_step");
   if (rc) return rc;
@@ -963,12 +750,10 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   const int max_steps = (warm > 0 ? warm : 0) + 2 * env->cfg.substeps + 8;
   if (int rcp = sync_params(env)) return rcp;
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
-  const bool dg = need_diag(env);
-  switch (env->cpl) {
-#define LAUNCH(c) case c: if (dg) hipLaunchKernelGGL((k_agent_step<c, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); else hipLaunchKernelGGL((k_agent_step<c, false>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break
-    case 0: hipLaunchKernelGGL((k_agent_step<0, true>), dim3(env->E), dim3(kThreads), env->lds_bytes, env->stream, (const StepParams *)env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
-    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
-#undef LAUNCH
+  switch (env->cpl == 0 ? 1 : launch_mode(env)) {
+    case 1: afc::launch_agent_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
+    case 2: afc::launch_agent_step_perf(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
+    default: afc::launch_agent_step_prod(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps);
   }
   int rc = launch_check("k_agent_step");
   if (rc) return rc;
@@ -1222,10 +1007,10 @@ int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const fl
   HIP_TRY(hipMemcpy(G(P.uy), fy, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0x), u0x, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0y), u0y, bytes, hipMemcpyHostToDevice));
-  if (need_diag(env))
-    hipLaunchKernelGGL(k_op_advdif<true>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
+  if (need_diag(env) || P.impl == 0)
+    afc::launch_op_advdif_diag(env->lds_bytes, env->stream, P);
   else
-    hipLaunchKernelGGL(k_op_advdif<false>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, P);
+    afc::launch_op_advdif_prod(env->lds_bytes, env->stream, P);
   int rc = launch_check("k_op_advdif");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
@@ -1265,10 +1050,10 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   float *dl = env->d_f1;
   StepParams Pq = P;
   Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
-  if (need_diag(env))
-    hipLaunchKernelGGL(k_op_mg<true>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
+  if (need_diag(env) || P.impl == 0)
+    afc::launch_op_mg_diag(env->lds_bytes, env->stream, Pq, dit, dl);
   else
-    hipLaunchKernelGGL(k_op_mg<false>, dim3(1), dim3(kThreads), env->lds_bytes, env->stream, Pq, dit, dl);
+    afc::launch_op_mg_prod(env->lds_bytes, env->stream, Pq, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));

@@ -1,19 +1,42 @@
 // bdim_v2.h -- the optimised phases of the per-env BDIM step (bdim_v2_body.h), compiled twice:
 //   afc::prod  the shipped instantiation: no experiment switches, no phase marks, no stop codes, no gates
+//   afc::perf  the shipped code with the red-black smoother (perf mode, see below)
 //   afc::diag  the same code with the diagnostics of tools/ compiled in (StepParams.dbg, Prof marks, stop codes,
 //              streaming gates); selected at launch time when cfg.reserved[0] != 0, a start stagger is configured or
 //              phase profiling is enabled.
 #pragma once
 #include "bdim_device.h"
 
+// AFC_ONLY_MODE (0 / 1 / 2) restricts the header to one instantiation (the step-kernel translation units)
+#if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 0
 #define AFC_DIAG 0
+#define AFC_RB 0
 #define AFC_NS prod
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
+#undef AFC_RB
 #undef AFC_NS
+#endif
 
+#if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 1
 #define AFC_DIAG 1
+#define AFC_RB 0
 #define AFC_NS diag
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
+#undef AFC_RB
 #undef AFC_NS
+#endif
+
+// afc::perf: PERF MODE (cfg.gs_mode = 1): MG.smooth's four Gauss-Seidel sweeps in red-black order by all four waves
+// instead of the reference's lexicographic order by one marching wave -- a different (equally convergent) smoother, so
+// results agree with the reference to a tolerance, not bit for bit.  Never the headline number.
+#if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 2
+#define AFC_DIAG 0
+#define AFC_RB 1
+#define AFC_NS perf
+#include "bdim_v2_body.h"
+#undef AFC_DIAG
+#undef AFC_RB
+#undef AFC_NS
+#endif

@@ -53,21 +53,26 @@ typedef __attribute__((address_space(3))) f2u lds_f2;
   "v_add_f32 %0, %0, %1\n\t"                                                 \
   "v_sub_f32 %0, %0, %10"
 // UNI: the four coefficients are wave-uniform (scalar registers).  FIN: also the final d = -(...)*inv.
+// `w` is read-write and overwritten by the first instruction while the other inputs are read later: it is marked
+// early-clobber so that it can never share a register with an input the compiler proves equal.  The two leading
+// multiplies are the wait states between the producer of `prev` (the instruction right before the block: the block is
+// asm volatile and `prev` is the previous block's output) and its DPP read; tests/test_build_resources.py checks the
+// mul / mul / mul_dpp pattern in the shipped disassembly.
 template <bool UNI, bool FIN>
 __device__ __forceinline__ float gs_core(float prev, float w, float dE, float dN, float r, float lw, float le, float ls,
                                          float ln, float iv) {
   float a, b;
   if (UNI && FIN)
     asm volatile(GS_CORE_ASM "\n\tv_mul_f32_e64 %0, %12, -%0"
-                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "+&v"(w), "=&v"(a), "=&v"(b)
                  : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw), "v"(iv));
   else if (UNI)
     asm volatile(GS_CORE_ASM
-                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "+&v"(w), "=&v"(a), "=&v"(b)
                  : "v"(prev), "v"(dE), "v"(dN), "s"(lw), "s"(le), "s"(ls), "s"(ln), "v"(r), "v"(lw));
   else
     asm volatile(GS_CORE_ASM
-                 : "+v"(w), "=&v"(a), "=&v"(b)
+                 : "+&v"(w), "=&v"(a), "=&v"(b)
                  : "v"(prev), "v"(dE), "v"(dN), "v"(lw), "v"(le), "v"(ls), "v"(ln), "v"(r), "v"(lw));
   return w;
 }
@@ -1045,6 +1050,57 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
   }
 }
 
+// Strip geometry of the up-leg: a strip brings kStripH new rows into the rings; the smoother runs in stages whose row
+// ranges are shifted up by one row each (stage s covers rows I0-s .. I0-s+kStripH-1), kStageShift = stages - 1.
+//   reference order: 4 stages = the 4 sweeps, run by the march as one fused pass
+//   perf mode:       8 stages = the 8 colour half-sweeps of 4 red-black sweeps
+#if AFC_RB
+constexpr int kStripH = 12, kStageShift = 7;
+#else
+constexpr int kStripH = 16, kStageShift = 3;
+#endif
+
+#if AFC_RB
+// PERF MODE smoother: half-sweep h (0..7) of four red-black Gauss-Seidel sweeps on rows I0-h .. I0-h+kStripH-1 of the
+// rings, by all threads: the cells with (i + j) & 1 == (h & 1) take
+//   d = -(d[i-1][j]*lw + d[i+1][j]*le + d[i][j-1]*ls + d[i][j+1]*ln - r) * inv        (MG.pde:84-88)
+// from their four neighbours of the other colour, which hold the values of half-sweep h-1 (rows below the strip of
+// stage h were covered by stage h-1 one row further down; rows above it have not seen stage h+1 yet).  Out-of-domain
+// neighbours read as 0, like in the march.  One LDS barrier per stage (the caller's).
+__device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int PW, int I0, int h, bool special,
+                                   const DescU &du) {
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
+  const int half = m_ >> 1;  // cells of one colour per row (a power of two on every level of the 16:8 grids)
+  const int c = h & 1;
+  const LevelDesc &D = *L.desc;
+  const bool pow2 = (half & (half - 1)) == 0;
+  const int sh = 31 - __builtin_clz(half);
+  const float cu = du.cu;
+  for (int q = threadIdx.x; q < kStripH * half; q += kThreads) {
+    const int rw = pow2 ? (q >> sh) : (q / half), qq = q - rw * half;
+    const int i = I0 - h + rw;
+    if (i < 1 || i > n_) continue;
+    const int j = 1 + 2 * qq + ((c + i + 1) & 1);
+    const int so = (i % kRing) * PW + j;
+    const float dW = (i > 1) ? dr[((i - 1) % kRing) * PW + j] : 0.f;
+    const float dE = (i < n_) ? dr[((i + 1) % kRing) * PW + j] : 0.f;
+    const float dS = dr[so - 1], dN = dr[so + 1];  // ghost columns of the ring hold 0
+    float v;
+    if (special) {
+      const int k = i * m + j;
+      v = -(dW * L.lx[k] + dE * L.lx[k + m] + dS * L.ly[k] + dN * L.ly[k + 1] - rr[so]) * L.inv[k];
+    } else {
+      // away from the bodies every face coefficient is cu (a zeroed boundary face multiplies a neighbour that reads
+      // as 0 anyway); only the inverse diagonal knows about the boundary (coarse levels)
+      float iv = du.iv0;
+      if (du.zb) iv = D.invtab[3 * ((i == 1) ? 1 : ((i == n_) ? 2 : 0)) + ((j == 1) ? 1 : ((j == m_) ? 2 : 0))];
+      v = -(dW * cu + dE * cu + dS * cu + dN * cu - rr[so]) * iv;
+    }
+    dr[so] = v;
+  }
+}
+#endif
+
 // One call = everything a level does on the way up (MG.pde:73-76 seen from the level itself):
 //   HASC:  d = prolongate(coarse.x); increment()            [x += d, r -= A d]
 //   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
@@ -1083,9 +1139,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;
   lds_barrier();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
-  for (int I0 = 1; I0 - 3 <= n_; I0 += 16) {
-    // ---- fill rows loaded+1 .. I0+16: r (after the prolongation increment) and d0 = r*inv ----
-    const int hi = I0 + 16;
+  for (int I0 = 1; I0 - kStageShift <= n_; I0 += kStripH) {
+    // ---- fill rows loaded+1 .. I0+kStripH: r (after the prolongation increment) and d0 = r*inv ----
+    const int hi = I0 + kStripH;
     const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
     if (chunked) {
       // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
@@ -1135,6 +1191,15 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     loaded = hi;
     lds_barrier();
     if (mk) pf.mark(PF_UP0);
+#if AFC_RB
+    {
+      const bool special = (I0 + kStripH >= du.sp_i0) && (I0 - kStageShift - 1 <= du.sp_i1);
+      for (int h = 0; h <= kStageShift; ++h) {
+        gs_rb_stage(F, rr, dr, PW, I0, h, special, du);
+        lds_barrier();
+      }
+    }
+#else
     if (tid < 64) {
       const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
@@ -1147,9 +1212,11 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
       __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();
+#endif
     if (mk) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
-    const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + 12 >= n_) ? n_ : I0 + 11;
+    const int e0 = (I0 - kStageShift - 1 < 1) ? 1 : I0 - kStageShift - 1,
+              e1 = (I0 + kStripH - kStageShift - 1 >= n_) ? n_ : I0 + kStripH - kStageShift - 2;
     const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
     if (chunked) {
       if (grp_on)
@@ -1357,12 +1424,14 @@ __device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *D
         seen = *pprod;                                                                                            \
       }                                                                                                           \
     }                                                                                                             \
+    asm volatile("" ::: "memory"); /* the prefetches below must not be hoisted above the wait (volatile orders only volatile) */ \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
       nR[e] = pR[tau0_ + 4 + e];                                                                                  \
       nE[e] = pE[tau0_ + 4 + e];                                                                                  \
       nN[e] = pN[tau0_ + 4 + e];                                                                                  \
     }                                                                                                             \
     if (consumer) seen = *pprod; /* for the next chunk: usually already far enough */                             \
+    asm volatile("" ::: "memory");                                                                                \
     float le4[4] = {0.f, 0.f, 0.f, 0.f};                                                                          \
     if (!FAST) {                                                                                                  \
       MW_COEF(tau0_ + 4, n_lw, n_ls, n_iv, n_ln4)                                                                 \

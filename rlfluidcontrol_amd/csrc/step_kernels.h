@@ -1,0 +1,281 @@
+// step_kernels.h -- the step kernels and their launchers for ONE instantiation of the optimised phases.  Included by
+// step_prod.hip / step_diag.hip / step_perf.hip, which define AFC_MODE (0 / 1 / 2) and AFC_MODE_NS (prod / diag / perf)
+// first: three translation units that build in parallel, each with its own device code object.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "bdim_device.h"
+#define AFC_ONLY_MODE AFC_MODE
+#include "bdim_v2.h"
+#include "step_launch.h"
+
+namespace {
+
+using afc::EnvScalars;
+using afc::G;
+using afc::kThreads;
+using afc::StepParams;
+
+// ---------------- kernels ----------------
+// CPL = columns per lane of the optimised kernels (grid height m-2 <= 64*CPL); CPL = 0 selects the
+// straightforward reference kernels.  One instantiation per CPL keeps each kernel's register
+// budget at 4 workgroups (16 waves) per CU.
+// MODE names the instantiation of the optimised phases this translation unit carries (AFC_MODE / AFC_MODE_NS, see
+// bdim_v2.h): 0 = shipped, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; cfg.gs_mode = 1).
+template <int CPL, int MODE>
+__device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
+                                              double *sm, afc::ShBcast *sh, float *lds) {
+  if constexpr (CPL == 0)
+    afc::sim_step(P, e, a, b, sm, sh);
+  else
+    afc::AFC_MODE_NS::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
+}
+
+template <int CPL, int MODE>
+__global__ __launch_bounds__(afc::kThreads, 4) void k_sim_step(const StepParams *__restrict__ Pp,
+                                                               const float *__restrict__ xi_m,
+                                                               float *__restrict__ force) {
+  constexpr bool DIAG = (MODE == 1);
+  const StepParams &P = *Pp;  // parameters live in device memory: phase functions take them by reference
+  __shared__ double sm[afc::kThreads];
+  __shared__ afc::ShBcast sh;
+  extern __shared__ float lds_dyn[];
+  const size_t e = blockIdx.x;
+  const float a = xi_m[2 * e], b = xi_m[2 * e + 1];
+  float pshift = G(P.sc)[e].p_shift;
+  if (DIAG) afc::gate_init(P);
+  __syncthreads();
+  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_acquire(P);
+  step_dispatch<CPL, MODE>(P, e, a, b, &pshift, sm, &sh, lds_dyn);
+  if (DIAG && CPL != 0 && !((P.dbg >> 12) & 15)) afc::gate_release(P, true);
+  if (threadIdx.x == 0) {
+    EnvScalars &s = G(P.sc)[e];
+    s.p_shift = pshift;
+    s.xi1_m = a;
+    s.xi2_m = b;
+    s.t += P.dt / P.resolution;  // AFCCylinder.pde:56
+    s.force_x = sh.fx;
+    s.force_y = sh.fy;
+    s.iters[0] = sh.it0;
+    s.iters[1] = sh.it1;
+    s.resid[0] = sh.r0;
+    s.resid[1] = sh.r1;
+    s.sim_steps += 1;
+    s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;  // clamped: diagnostic launches that leave the step early
+    s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;  // do not fill sh
+    if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
+    if (force) {
+      force[2 * e] = sh.fx;
+      force[2 * e + 1] = sh.fy;
+    }
+  }
+}
+
+// The body of draw() (clientCFD.pde:35-56) repeated until the next action request.
+template <int CPL, int MODE>
+__global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParams *__restrict__ Pp,
+                                                                 const float *__restrict__ action,
+                                                                 float *__restrict__ obs, float *__restrict__ reward,
+                                                                 uint8_t *__restrict__ done, int *__restrict__ nsteps,
+                                                                 int max_steps) {
+  constexpr bool DIAG = (MODE == 1);
+  const StepParams &P = *Pp;
+  __shared__ double sm[afc::kThreads];
+  __shared__ afc::ShBcast sh;
+  extern __shared__ float lds_dyn[];
+  const size_t e = blockIdx.x;
+  if (DIAG && P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
+    const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
+    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);
+  }
+  // the env's episode scalars live in LDS for the whole launch (thread 0 does the bookkeeping of
+  // clientCFD.pde:35-56, everybody reads what the control flow needs): no per-thread register copies
+  __shared__ EnvScalars s;
+  __shared__ int s_stop;
+  const float a1 = action[2 * e], a2 = action[2 * e + 1];
+  if (threadIdx.x == 0) {
+    s = G(P.sc)[e];
+    s.xi1 = a1;  // clientCFD.pde:51-54
+    s.xi2 = a2;
+    s.xi1_m = P.act_scale * s.xi1;
+    s.xi2_m = P.act_scale * s.xi2;
+    s.window_done = 0;
+    s_stop = 0;
+  }
+  if (DIAG) afc::gate_init(P);
+  __syncthreads();
+  if (DIAG && CPL != 0) afc::gate_acquire(P);
+  const float xi1_m = afc::AFC_MODE_NS::uni(s.xi1_m), xi2_m = afc::AFC_MODE_NS::uni(s.xi2_m);
+  float pshift = s.p_shift;
+  int steps = 0;
+  long long dbg_t0 = 0;
+  while (steps < max_steps) {
+    if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
+    if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
+    step_dispatch<CPL, MODE>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
+    ++steps;
+    if (threadIdx.x == 0) {
+      s.t += P.dt / P.resolution;
+      s.force_x = sh.fx;
+      s.force_y = sh.fy;
+      s.iters[0] = sh.it0;
+      s.iters[1] = sh.it1;
+      s.resid[0] = sh.r0;
+      s.resid[1] = sh.r1;
+      s.sim_steps += 1;
+      s.it_hist[afc::clampi(sh.it0, 1, 8) - 1] += 1;
+      s.it_hist[afc::clampi(sh.it1, 1, 8) - 1] += 1;
+      if (!(isfinite(sh.fx) && isfinite(sh.fy))) s.diverged = 1;
+      if (s.t > P.init_time) {  // clientCFD.pde:39-47
+        s.callLearn--;
+        s.Cd += sh.fx;
+        s.Cl += sh.fy;
+        if (s.callLearn <= 0) {
+          s.callLearn = P.substeps;
+          s.Cd = s.Cd / s.callLearn * 2 / P.resolution;
+          s.Cl = s.Cl / s.callLearn * 2 / P.resolution;
+          s.obs_cl = s.Cl;
+          s.obs_cd = s.Cd;
+          if (!P.carry_quirk) {
+            s.Cd = 0.f;
+            s.Cl = 0.f;
+          }
+          s.window_done = 1;
+          s_stop = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_stop) break;
+  }
+  if (DIAG && CPL != 0) afc::gate_release(P, true);
+  if (threadIdx.x == 0) {
+    s.p_shift = pshift;
+    G(P.sc)[e] = s;
+    obs[2 * e] = s.obs_cl;  // wire order is Cl then Cd (clientCFD.pde:120)
+    obs[2 * e + 1] = s.obs_cd;
+    const float aa1 = afc::jabs(a1), aa2 = afc::jabs(a2);
+    reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
+    done[e] = (!(s.t < P.end_time)) ? 1 : 0;
+    if (nsteps) nsteps[e] = steps;
+    if (DIAG && (P.dbg & 8)) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
+      obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
+      obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
+    }
+  }
+}
+
+// unit-level operators on env 0 (same device functions as the step)
+template <int MODE>
+__global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
+  extern __shared__ float lds_dyn[];
+  if (P.impl == 0) {
+    afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
+    return;
+  }
+  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {  // F starts as a copy of u (VectorField.pde:171)
+    G(P.fx)[k] = G(P.ux)[k];
+    G(P.fy)[k] = G(P.uy)[k];
+  }
+  __syncthreads();
+  const int m_ = P.m - 2;
+#define ADV(c) afc::AFC_MODE_NS::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn)
+  if (m_ <= 64) ADV(1);
+  else if (m_ <= 128) ADV(2);
+  else if (m_ <= 192) ADV(3);
+  else ADV(4);
+#undef ADV
+}
+template <int MODE>
+__global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iters, float *linf) {
+  __shared__ double sm[afc::kThreads];
+  // b is staged in fx; x in p.  r = b - A x  (MG.pde:51)
+  const afc::Lv L0 = afc::make_level(P, 0, 0);
+  const int n = P.n, m = P.m;
+  for (int k = threadIdx.x; k < P.N; k += afc::kThreads) {
+    const int i = k / m, j = k - i * m;
+    float rv = G(P.fx)[k];  // b.minus(A.times(x)): ghosts of A x are 0 -> r ghost = b ghost
+    if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+      const float lw = L0.lx[k], le = L0.lx[k + m], ls = L0.ly[k], ln = L0.ly[k + 1];
+      const float diag = -(lw + le + ls + ln);
+      const float *p = G(P.p);
+      rv = G(P.fx)[k] - (p[k] * diag + p[k - m] * lw + p[k + m] * le + p[k - 1] * ls + p[k + 1] * ln);
+    }
+    G(P.r)[k] = rv;
+  }
+  __syncthreads();
+  float l;
+  extern __shared__ float lds_dyn[];
+  int it;
+  if (P.impl == 0) {
+    afc::Prof pf;
+    pf.start(P);
+    it = afc::mg_solve(P, 0, sm, &l, pf);
+  } else {
+    afc::Lv L0v = afc::make_level(P, 0, 0);
+    L0v.d = G(P.u0y);
+    float xs;
+    afc::AFC_MODE_NS::ProfT pf;
+    pf.start(P);
+    it = afc::AFC_MODE_NS::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+  }
+  if (threadIdx.x == 0) {
+    *iters = it;
+    *linf = l;
+  }
+}
+
+
+}  // namespace
+
+namespace afc {
+
+#define AFC_CAT2(a, b) a##b
+#define AFC_CAT(a, b) AFC_CAT2(a, b)
+#define AFC_FN(name) AFC_CAT(name, AFC_MODE_NS)
+
+// CPL = 0 (the straightforward reference kernels) exists in the diagnostic translation unit only
+void AFC_FN(launch_sim_step_)(int cpl, int E, size_t lds, hipStream_t st, const StepParams *dP, const float *dxi,
+                              float *dforce) {
+  switch (cpl) {
+#define LAUNCH(c) case c: hipLaunchKernelGGL((k_sim_step<c, AFC_MODE>), dim3(E), dim3(kThreads), lds, st, dP, dxi, dforce); break
+#if AFC_MODE == 1
+    LAUNCH(0);
+#endif
+    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#undef LAUNCH
+  }
+}
+void AFC_FN(launch_agent_step_)(int cpl, int E, size_t lds, hipStream_t st, const StepParams *dP, const float *dact,
+                                float *dobs, float *drew, uint8_t *ddone, int *dns, int max_steps) {
+  switch (cpl) {
+#define LAUNCH(c) case c: hipLaunchKernelGGL((k_agent_step<c, AFC_MODE>), dim3(E), dim3(kThreads), lds, st, dP, dact, dobs, drew, ddone, dns, max_steps); break
+#if AFC_MODE == 1
+    LAUNCH(0);
+#endif
+    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+#undef LAUNCH
+  }
+}
+#if AFC_MODE != 2
+void AFC_FN(launch_op_advdif_)(size_t lds, hipStream_t st, const StepParams &P) {
+  hipLaunchKernelGGL(k_op_advdif<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P);
+}
+void AFC_FN(launch_op_mg_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl) {
+  hipLaunchKernelGGL(k_op_mg<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl);
+}
+#endif
+#if AFC_MODE == 1
+int occupancy_agent_step_diag(int cpl, size_t lds, int *per_cu) {
+  switch (cpl) {
+#define OCC(c) case c: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_agent_step<c, 1>, kThreads, lds) == hipSuccess ? 0 : -1
+    OCC(1); OCC(2); OCC(3); OCC(4);
+#undef OCC
+  }
+  return -1;
+}
+#endif
+
+}  // namespace afc

@@ -6,6 +6,7 @@ creating an env raises unless the HIP extension is built and a GPU is visible.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -37,7 +38,8 @@ class AfcConfig(C.Structure):
         ("theta", C.c_float), ("act_scale", C.c_float), ("substeps", C.c_int32),
         ("init_time", C.c_float), ("end_time", C.c_float), ("num_envs", C.c_int32),
         ("device", C.c_int32), ("mg_max_iters", C.c_int32), ("carry_quirk", C.c_int32),
-        ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("impl", C.c_int32), ("stagger_us", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("impl", C.c_int32), ("stagger_us", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("gs_mode", C.c_int32), ("reserved2", C.c_int32 * 2),
     ]
 
 
@@ -105,8 +107,16 @@ def default_config(**overrides):
     L = load_library()
     cfg = AfcConfig()
     L.afc_default_config(C.byref(cfg))
-    if os.environ.get("AFC_DBG"):  # development: run any program (e.g. the test suite) with experiment switches on
-        cfg.reserved[0] = int(os.environ["AFC_DBG"], 0)
+    # development: AFC_DBG=<switches> runs any program (e.g. the test suite) on an experiment path -- but only together
+    # with AFC_DBG_ENABLE=1, so that a stray or inherited AFC_DBG cannot silently change physics or benchmark numbers
+    if os.environ.get("AFC_DBG"):
+        if os.environ.get("AFC_DBG_ENABLE") == "1":
+            cfg.reserved[0] = int(os.environ["AFC_DBG"], 0)
+            print("rlfluidcontrol_amd: AFC_DBG=%s is ON (development switches; results are not the product's)"
+                  % os.environ["AFC_DBG"], file=sys.stderr)
+        else:
+            print("rlfluidcontrol_amd: AFC_DBG=%s ignored (set AFC_DBG_ENABLE=1 to honour it)" % os.environ["AFC_DBG"],
+                  file=sys.stderr)
     for k, v in overrides.items():
         if k == "dbg":  # experiment switches (reserved[0])
             cfg.reserved[0] |= int(v)

@@ -137,15 +137,34 @@ class ReplayBuffer:
                     rews=self.rews_buf[:n].cpu(), done=self.done_buf[:n].cpu(), ptr=self.ptr, size=self.size,
                     max_size=self.max_size)
 
-    def load_state_dict(self, sd):
+    def check_state_dict(self, sd):
+        """raises if the checkpointed buffer cannot be restored into this one (nothing is modified)"""
         n = int(sd["size"])
-        if int(sd.get("max_size", self.max_size)) != self.max_size or n > self.max_size or not (0 <= int(sd["ptr"]) < self.max_size):
-            raise ValueError("replay buffer checkpoint (max_size %s, size %s, ptr %s) does not fit a buffer of %d"
-                             % (sd.get("max_size"), sd["size"], sd["ptr"], self.max_size))
+        if n > self.max_size or n < 0:
+            raise ValueError("replay buffer checkpoint holds %d transitions, this buffer %d at most" % (n, self.max_size))
+        for key, buf in (("obs1", self.obs1_buf), ("obs2", self.obs2_buf), ("acts", self.acts_buf), ("rews", self.rews_buf),
+                         ("done", self.done_buf)):
+            if tuple(sd[key].shape) != (n,) + tuple(buf.shape[1:]):
+                raise ValueError("replay buffer checkpoint: %s has shape %s, expected %s"
+                                 % (key, tuple(sd[key].shape), (n,) + tuple(buf.shape[1:])))
+
+    def load_state_dict(self, sd):
+        """The reference restores by replacing the buffer object wholesale (server.py:192-198), so any pickled buffer
+        restores there; here any checkpoint whose CONTENT fits is accepted, whatever capacity it was saved from: the
+        saved transitions are the oldest-to-newest prefix and the write pointer follows them."""
+        self.check_state_dict(sd)
+        n = int(sd["size"])
+        same = int(sd.get("max_size", self.max_size)) == self.max_size
+        if same:
+            order = torch.arange(n)
+        else:  # a full buffer of another capacity is a ring: unroll it so that index 0 is the oldest transition
+            old_max, ptr = int(sd.get("max_size", n)), int(sd["ptr"])
+            order = (torch.arange(n) + (ptr if n == old_max else 0)) % max(n, 1)
         for name, key in (("obs1_buf", "obs1"), ("obs2_buf", "obs2"), ("acts_buf", "acts"), ("rews_buf", "rews"),
                           ("done_buf", "done")):
-            getattr(self, name)[:n] = sd[key].to(self.device)
-        self.ptr, self.size = int(sd["ptr"]), n
+            getattr(self, name)[:n] = sd[key][order].to(self.device)
+        self.size = n
+        self.ptr = int(sd["ptr"]) % self.max_size if same else n % self.max_size
 
 
 def _mlp(sizes, last):
@@ -166,7 +185,9 @@ class Agent:
     """agent_TD3.py:10-184.  `get_action`, `train_iter`, `record`, `reset_agent`, `reset_episode`
     keep the reference's names and meaning; states/actions may carry any batch size."""
 
-    def __init__(self, state_dim, action_dim, explore_noise="Gaussian", device="cpu", seed=None, num_envs=1):
+    def __init__(self, state_dim, action_dim, explore_noise="Gaussian", device="cpu", seed=None, num_envs=1, world=1):
+        self.world = world  # > 1: sharded learner (gradients averaged over the ranks, see _sync_grads)
+        self.n_grad_allreduce = 0
         self.lr, self.gamma, self.tau = 1e-4, 0.99, 0.005
         self.bs, self.bfs, self.d = 512, 1000000, 2
         self.explore_noise = explore_noise
@@ -199,6 +220,7 @@ class Agent:
             for p in t.parameters():
                 p.requires_grad_(False)
         critic_params = list(self.main_critic_1.parameters()) + list(self.main_critic_2.parameters())
+        self._critic_params = critic_params
         self.Q_opt = torch.optim.Adam(critic_params, lr=self.lr, eps=1e-8)
         self.P_opt = torch.optim.Adam(self.main_actor.parameters(), lr=self.lr, eps=1e-8)
 
@@ -235,18 +257,39 @@ class Agent:
         q_loss = ((self.main_critic_1(sa1) - y) ** 2).mean() + ((self.main_critic_2(sa1) - y) ** 2).mean()
         return q_loss, y
 
-    def train_iter(self):
-        if self.bs > self.replay_buffer.size:
+    def _sync_grads(self, params):
+        """sharded learner: every rank holds the transitions of its own envs and a 1/world share of the batch; the
+        gradients are averaged over the ranks (one all-reduce of the flattened gradients), so every rank applies the
+        same update to the same weights"""
+        if self.world <= 1:
             return
-        batch = self.replay_buffer.sample_batch(self.bs, generator=self.gen)
+        import torch.distributed as dist
+        params = [p for p in params if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat)
+        flat /= self.world
+        o = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+        self.n_grad_allreduce += 1
+
+    def train_iter(self):
+        bs = self.bs if self.world <= 1 else -(-self.bs // self.world)  # this rank's share of the batch
+        if bs > self.replay_buffer.size:
+            return
+        batch = self.replay_buffer.sample_batch(bs, generator=self.gen)
         q_loss, _ = self.losses(batch)
         self.Q_opt.zero_grad(set_to_none=True)
         q_loss.backward()
+        self._sync_grads(self._critic_params)
         self.Q_opt.step()
         if self.total_step_count % self.d == 0:
             p_loss = -self.main_critic_1(torch.cat([batch["obs1"], self.main_actor(batch["obs1"])], 1)).mean()
             self.P_opt.zero_grad(set_to_none=True)
             p_loss.backward()
+            self._sync_grads(list(self.main_actor.parameters()))
             self.P_opt.step()
             with torch.no_grad():  # T_op
                 for t, m in self._pairs:
@@ -278,6 +321,10 @@ class Agent:
                     total_step_count=self.total_step_count)
 
     def load_state_dict(self, sd):
+        self.replay_buffer.check_state_dict(sd["replay"])  # validate everything before the first mutation
+        for n in sd["nets"]:
+            if not hasattr(self, n):
+                raise ValueError("checkpoint has an unknown network %r" % n)
         for n, s in sd["nets"].items():
             getattr(self, n).load_state_dict(s)
         self.Q_opt.load_state_dict(sd["Q_opt"])
@@ -305,11 +352,17 @@ class BatchedLearner:
     act on the filtered obs of every env each agent step, keep the episode's records on the device,
     and at the end of the episode turn them into transitions and run `train_steps` TD3 iterations."""
 
-    def __init__(self, num_envs, device="cpu", filter="None", explore_noise="Gaussian", one_action=False, seed=None):
+    def __init__(self, num_envs, device="cpu", filter="None", explore_noise="Gaussian", one_action=False, seed=None,
+                 shard=None):
+        """num_envs = ALL envs this learner acts for (every rank evaluates the same actor on the gathered obs).
+        shard = (rank, world): the learner is sharded -- this rank stores the transitions of ITS envs only (the block
+        [rank*E, (rank+1)*E) of the env axis) and trains on a 1/world share of every batch with averaged gradients."""
         self.E = num_envs
+        self.rank, self.world = shard if shard is not None else (0, 1)
         self.one_action = one_action
         self.action_dim = 1 if one_action else 2
-        self.agent = Agent(2, self.action_dim, explore_noise=explore_noise, device=device, seed=seed, num_envs=num_envs)
+        self.agent = Agent(2, self.action_dim, explore_noise=explore_noise, device=device, seed=seed, num_envs=num_envs,
+                           world=self.world)
         self.filter = KalmanFilter() if filter == "Kalman" else NoneFilter()
         self.state_record, self.action_record = [], []
 
@@ -332,6 +385,10 @@ class BatchedLearner:
         if len(self.state_record) >= 2:
             s1, act, r, s2, done = assemble_transitions(torch.stack(self.state_record), torch.stack(self.action_record),
                                                         self.action_dim)
+            if self.world > 1:  # this rank keeps its own envs' transitions
+                per = self.E // self.world
+                sl = slice(self.rank * per, (self.rank + 1) * per)
+                s1, act, r, s2, done = s1[:, sl], act[:, sl], r[:, sl], s2[:, sl], done[:, sl]
             # time-major records -> one store per agent step keeps the reference's FIFO order per env
             for t in range(s1.shape[0]):
                 self.agent.replay_buffer.store(s1[t], act[t], r[t], s2[t], done[t])
