@@ -654,6 +654,9 @@ constexpr int kRing = 24;
 // two sweeps of a half-wave collide on 14 of 16 banks: every LDS access of the march took twice its cycles, which is
 // what kept a second marching wave per workgroup from paying -- tools/march_bench.hip).
 __device__ __host__ __forceinline__ int ring_pitch(int m) {
+#ifdef AFC_KPAD_FORCE  // tools/march_bench.hip only: a fixed pad (36 = the pitch of rounds 1-2) for comparison
+  return m + AFC_KPAD_FORCE;
+#endif
   const int lo = m + 34;
   return lo + ((12 - lo) & 31);
 }

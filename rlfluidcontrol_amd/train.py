@@ -11,11 +11,16 @@ replay buffer never leave HBM; at the end of an episode the E x 407 transitions 
 Multi-GPU (cfg5: 8 x MI355X): one process per GPU over RCCL,
     python -m rlfluidcontrol_amd.train --gpus 8 --envs 1024        (spawns the ranks itself), or
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m rlfluidcontrol_amd.train ...
-Every rank steps its shard, the one all-gather per agent step of `ShardedVecEnv` gives every rank the global
-observation, and the learner is REPLICATED (same seed, same inputs => same weights and actions on every
-rank), so no gradient collective is needed for a 0.2 M-parameter model.  The reference's only RL collective is
-the same shape: rank 0 talks to the agent and `MPI_Bcast`s the two action values
-(clientNektar/Fourier/src/drive.C:1561); here every rank evaluates the same actor on the same gathered obs.
+Every rank steps its shard and the one all-gather per agent step of `ShardedVecEnv` gives every rank the global
+observation; every rank evaluates the same actor on it (identical weights, identical generator state), the reference's
+only RL collective has the same shape (rank 0 asks the agent and `MPI_Bcast`s the two action values,
+clientNektar/Fourier/src/drive.C:1561).  The LEARNER IS SHARDED: a rank stores the transitions of its own envs only
+(E x 407 per episode -- the whole job's 8 x that would overflow the reference's 1 M-transition FIFO three times over at
+cfg5 scale) and trains on a 1/world share of every batch; the gradients are averaged with one all-reduce per optimiser
+step (~0.8 MB), so the weights stay bit-identical across ranks (tests/test_train_sharded_gloo.py).
+The rollout loop does not synchronise with the host per agent step: the number of agent steps of an episode is a
+function of the config alone (float32 time stepping, `episode_plan`), rewards are accumulated on the device, and the
+plan is checked against the device's `done` flags once, at the end.
 """
 import argparse
 import json
@@ -29,26 +34,72 @@ from . import td3
 from .vec_env import HipBackend, ShardedVecEnv
 
 
-def run_episode(vec, learner, max_requests=None, stochastic=True):
-    """One pass of the reference's draw() loop for all envs: returns (requests, mean reward per request)."""
+def episode_plan(resolution, t_step=0.0075, init_time=1.0, end_time=50.0, substeps=16):
+    """(agent-step calls, requests) of one episode started from t = 0 with a fresh averaging window, by the float32
+    bookkeeping of k_agent_step / clientCFD.pde:35-56: a call runs sim-steps until a window completes or t reaches
+    Time; a request follows every call whose window completed (408 requests)."""
+    import numpy as np
+    f = np.float32
+    dt = f(f(t_step) * f(resolution))
+    inc = f(dt / f(resolution))
+    t, cl, calls, requests = f(0), substeps, 0, 0
+    while t < f(end_time):
+        calls += 1
+        done_window = False
+        while t < f(end_time):
+            t = f(t + inc)
+            if t > f(init_time):
+                cl -= 1
+                if cl <= 0:
+                    cl = substeps
+                    done_window = True
+                    break
+        if done_window:
+            requests += 1
+    return calls, requests
+
+
+def run_episode(vec, learner, max_requests=None, stochastic=True, plan=None):
+    """One pass of the reference's draw() loop for all envs: returns (requests, mean reward per request).
+    plan = (calls, requests) from `episode_plan`: the loop then runs without a host synchronisation per agent step
+    (all envs run the same fixed-dt episode in lock-step); without it the device's `done` flags are polled."""
     W, E = vec.world, vec.E
     action = torch.zeros(W * E, 2, device=vec.device)
     learner.start_episode()
-    n, rew_sum = 0, 0.0
+    n = 0
+    rew_sum = torch.zeros((), device=vec.device)
+    if plan is not None:
+        calls, requests = plan
+        if max_requests is not None:
+            requests = min(requests, max_requests)
+        done = None
+        for c in range(calls):
+            obs, rew, done = vec.step(action)
+            # a window that completes on the step that takes t to Time is still sent by the reference
+            # (clientCFD.pde:36-56), one cut short by t >= Time is not: `requests` knows which it is
+            if n >= requests:
+                break
+            action = learner.request_action(obs, stochastic=stochastic)
+            if n > 0:
+                rew_sum += rew.mean()
+            n += 1
+            if max_requests is not None and n >= max_requests:
+                break
+        if max_requests is None and not bool(done.all()):  # the one host synchronisation of the rollout
+            raise RuntimeError("episode plan (%d calls) and the device disagree: envs are not done" % calls)
+        return n, float(rew_sum) / max(n - 1, 1)
     while True:
         obs, rew, done = vec.step(action)
         ended = bool(done.all())
-        # all envs run the same fixed-dt episode in lock-step; a window that completes on the step that takes t
-        # to Time is still sent by the reference (clientCFD.pde:36-56), one cut short by t >= Time is not
         if ended and not vec.window_complete():
             break
         action = learner.request_action(obs, stochastic=stochastic)
         if n > 0:
-            rew_sum += float(rew.mean())
+            rew_sum += rew.mean()
         n += 1
         if ended or (max_requests is not None and n >= max_requests):
             break
-    return n, rew_sum / max(n - 1, 1)
+    return n, float(rew_sum) / max(n - 1, 1)
 
 
 def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=1000, device="cuda:0", seed=0,
@@ -67,14 +118,19 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
     if init is not None:
         g.set_reset_state(init["u"], init["v"], init["p"])
     vec = ShardedVecEnv(HipBackend(g, dev), num_envs, device=dev)
-    learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed)
+    learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed,
+                                 shard=(vec.rank, vec.world))
     if batch_size:
         learner.agent.bs = batch_size
+    c = g.cfg
+    # the sketch globals (callLearn, Cd, Cl) survive an episode roll-over in the reference's carry mode: the phase of the
+    # averaging window then depends on history, and the loop polls the device instead of following a plan
+    plan = None if c.carry_quirk else episode_plan(c.resolution, c.t_step, c.init_time, c.end_time, c.substeps)
     history = []
     for ep in range(episodes):
         g.reset()
         t0 = time.time()
-        n, mean_r = run_episode(vec, learner, max_requests=max_requests)
+        n, mean_r = run_episode(vec, learner, max_requests=max_requests, plan=plan)
         torch.cuda.synchronize(dev)
         t1 = time.time()
         learner.train(train_steps)
@@ -82,7 +138,8 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
         t2 = time.time()
         rec = dict(episode=ep + 1, requests=n, mean_reward=mean_r, rollout_s=t1 - t0, train_s=t2 - t1,
                    buffer=learner.agent.replay_buffer.size, td3_iters=learner.agent.total_step_count,
-                   world=vec.world, envs_total=vec.world * num_envs, collectives=vec.n_collectives)
+                   world=vec.world, envs_total=vec.world * num_envs, collectives=vec.n_collectives,
+                   grad_allreduces=learner.agent.n_grad_allreduce)
         history.append(rec)
         log(json.dumps(rec))
     g.close()

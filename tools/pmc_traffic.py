@@ -6,7 +6,11 @@ the step kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM presc
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (ties the figure to the kernel sources it was measured on)
 
 
 def steady(path, counter):
@@ -21,6 +25,7 @@ write_kib = steady(sys.argv[2], "WRITE_SIZE")
 out = {"kernel": "k_agent_step", "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
        "fetch_bytes_corrected_x2": 2 * fetch_kib * 1024, "write_bytes": write_kib * 1024,
        "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+       "kernel_src_sha16": kernel_source_hash(),
        "note": "steady launches (16 sim-steps x 1024 envs, 256x128); FETCH_SIZE doubled per the gfx950 correction "
                "(upper estimate: part of our loads are 4- and 8-byte wide, for which the counter is uncalibrated)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
