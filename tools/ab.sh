@@ -1,9 +1,14 @@
 #!/bin/bash
-# same-box A/B of two builds of the library: tools/bin/libafc_base.so (reference) vs the in-tree one
-# usage: tools/ab.sh [rounds] [extra bench args]
+# same-box A/B of builds of the library: tools/ab.sh [rounds] [lib ...]   (default: tools/bin/libafc_base.so vs the in-tree one)
+# each round runs every library once, alternating, so that box drift hits all of them alike
 R=${1:-3}; shift
+LIBS=("$@")
+[ ${#LIBS[@]} -eq 0 ] && LIBS=(tools/bin/libafc_base.so rlfluidcontrol_amd/libafc_env.so)
 for i in $(seq $R); do
-  a=$(AFC_ENV_LIB=tools/bin/libafc_base.so timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/')
-  b=$(timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/')
-  echo "base $a  new $b"
+  line=""
+  for L in "${LIBS[@]}"; do
+    v=$(AFC_ENV_LIB=$L timeout 300 python bench.py --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/')
+    line="$line $(basename $L .so) $v"
+  done
+  echo "$line"
 done
