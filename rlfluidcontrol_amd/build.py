@@ -25,7 +25,7 @@ def _deps():
 # -fno-slp-vectorize: left to itself the SLP vectoriser pairs scalar float operations into v_pk_*_f32 and pays for it
 # in register moves (every phase here is bound by VALU issue); packed arithmetic is written out where it pays
 # (the QUICK faces of advdif_v2).  Measured +2 % on the whole step.
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+FLAGS = (os.environ.get("AFC_EXTRA_FLAGS", "").split()) + ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 

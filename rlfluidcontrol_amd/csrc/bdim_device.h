@@ -107,6 +107,7 @@ struct StepParams {
   int adv_ns;          // ring depth (rows) of advdif_v3's per-wave row pipelines; 0 = use advdif_v2
   int head_v3;         // 1: the barrier-free head of the pressure solve (grids of 128 interior columns)
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
+  int up2;             // 1: up-legs with two strips per round and two marching waves (mg_up_smooth2)
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
 };

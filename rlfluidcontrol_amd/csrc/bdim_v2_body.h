@@ -137,6 +137,20 @@ __device__ __forceinline__ F4 load4u(const float *p) {  // 4-byte-aligned 16-byt
 }
 __device__ __forceinline__ void store4u(float *p, const F4 &v) { __builtin_memcpy(p, &v, 16); }
 
+// 16-byte access at a 32-bit byte offset from a wave-uniform base: global_* with the base in SGPRs, no 64-bit lane address
+__device__ __forceinline__ F4 ld4b(const float *base, unsigned boff) {
+  F4 r;
+  __builtin_memcpy(&r, (const char *)base + boff, 16);
+  return r;
+}
+__device__ __forceinline__ float ld1b(const float *base, unsigned boff) {
+  float r;
+  __builtin_memcpy(&r, (const char *)base + boff, 4);
+  return r;
+}
+__device__ __forceinline__ void st4b(float *base, unsigned boff, const F4 &v) { __builtin_memcpy((char *)base + boff, &v, 16); }
+__device__ __forceinline__ void st1b(float *base, unsigned boff, float v) { __builtin_memcpy((char *)base + boff, &v, 4); }
+
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
 // flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
@@ -826,6 +840,193 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
 #undef GS_CHUNK
 }
 
+// The march for TWO STRIPS IN FLIGHT (mg_up_smooth2): the d ring holds kRing2 rows, r (after the prolongation
+// increment) is not in LDS at all -- every lane streams its row of it from global memory (rg: the level's `d` scratch
+// array, written by the fill; 16 bytes per lane and 4-step chunk, fetched two chunks ahead into the operand set that has
+// just been used up) -- and two waves march consecutive strips: SYNC 1 = the wave of the upper strip publishes the steps
+// it has completed in an LDS word (after its stores: the LDS operations of a wave execute in order), SYNC 2 = the wave
+// of the lower strip follows at kFollow steps: its first row needs the upper strip's last row of the same sweep (15
+// steps behind that strip's first row) and its operand fetches run up to 8 steps ahead of their use.
+constexpr int kRing2 = 40;
+constexpr int kFollow = 32;
+template <bool FAST, bool ZB, int SYNC>
+__device__ __forceinline__ void gs_march4(const Lv &L, const float *rg, float *dr, float *zrow, float *dummy, int I0,
+                                          volatile lds_i *prog, int pbase) {
+  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = ring_pitch(m);
+  const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
+  const int i = I0 - k + c;
+  const bool row_ok = (i >= 1) && (i <= n_);
+  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);  // clamped for addressing only
+  const int slot = (ic % kRing2) * PW, slotE = ((ic + 1) % kRing2) * PW;
+  const LevelDesc &D = *L.desc;
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
+  if (FAST) {  // row-dependent part of the analytic inverse diagonal
+    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
+    iv0 = D.invtab[3 * rc + 0];
+    iv1 = D.invtab[3 * rc + 1];
+    iv2 = D.invtab[3 * rc + 2];
+  }
+  const float cu = uni(D.cu);
+  const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
+  // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
+  // iteration and possibly one more at the end
+  const int steps = (m_ + 15 + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
+  const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
+  // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
+  // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
+  // outside the grid read the zero row and write to the dummy row.
+  const int jo = 1 - c - kLag * k;
+  unsigned o_rv = 4u * (unsigned)((row_ok ? ic : 1) * m + jo);  // byte offset of this lane's r stream in rg (row 1 for idle lanes)
+  const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
+  const float *p_cW = (rowW_ok ? dr + ((i - 1) % kRing2) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
+  const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
+  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
+  float *w_d = (row_ok ? dr + slot : dummy) + jo;
+  // The five streams of a lane as LDS byte addresses that advance by one opaque add per loop iteration (8 steps): every
+  // access below is `base + immediate`, two consecutive steps per instruction (ds_read2_b32 / ds_write2_b32).
+  unsigned q_cW = lds_addr(p_cW), q_cN = lds_addr(p_cN), q_dE = lds_addr(p_dE), q_wd = lds_addr(w_d);
+#define LD2(q, o) (*(const lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)))
+#define ST2(q, o, v) (*(lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)) = (v))
+  float aR[4], aW[4], aN[4], aE[4], bR[4], bW[4], bN[4], bE[4];
+  int seen = 0;
+  if (SYNC == 2) {  // the very first operand fetch already reads what the upper strip must have finished
+    seen = *prog;
+    for (int spin_ = 0; seen < pbase + kFollow && spin_ < (1 << 18); ++spin_) {
+      __builtin_amdgcn_s_sleep(1);
+      seen = *prog;
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int h = 0; h < 4; h += 2) {
+    const f2u w2 = LD2(q_cW, h), n2 = LD2(q_cN, h), e2 = LD2(q_dE, h);
+    aW[h] = w2.x, aW[h + 1] = w2.y;
+    aN[h] = n2.x, aN[h + 1] = n2.y, aE[h] = e2.x, aE[h + 1] = e2.y;
+  }
+  {
+    const F4 ta = ld4b(rg, o_rv), tb = ld4b(rg, o_rv + 16u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aR[e] = ta.v[e], bR[e] = tb.v[e];
+  }
+  F4 a_lw, a_le, a_ls, a_iv, b_lw, b_le, b_ls, b_iv;
+  float a_ln4 = 0.f, b_ln4 = 0.f;
+  const int cbase = ic * m + jo;  // + tau = flat index of this lane's cell at step tau
+#define GS_CHUNK(TAU, lw_, le_, ls_, iv_, ln4_) \
+  {                                             \
+    int kk_ = cbase + (TAU);                    \
+    kk_ = kk_ < 0 ? 0 : kk_;                    \
+    lw_ = load4u(L.lx + kk_);                   \
+    le_ = load4u(L.lx + kk_ + m);               \
+    ls_ = load4u(L.ly + kk_);                   \
+    iv_ = load4u(L.inv + kk_);                  \
+    ln4_ = L.ly[kk_ + 4];                       \
+  }
+  if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
+  float res = 0.f;
+  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
+  // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
+  // fetched (what they need was stored kLag steps before its use, i.e. by the store just issued).  O = offset of the
+  // chunk from the iteration's base addresses; STEADY: no activity mask, interior inverse diagonal
+#define GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
+  _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                                                                   \
+    f2u out;                                                                                                           \
+    _Pragma("unroll") for (int e = h; e < h + 2; ++e) {                                                                \
+      float lw, le, ls, ln, iv;                                                                                        \
+      if (FAST) {                                                                                                      \
+        /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:       */ \
+        /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                     */ \
+        lw = le = ls = ln = cu;                                                                                        \
+        iv = iv0;                                                                                                      \
+        if (zb && !(STEADY)) {                                                                                         \
+          const int j = (T0) + jo + e;                                                                                 \
+          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                               \
+        }                                                                                                              \
+      } else {                                                                                                         \
+        lw = c_lw.v[e];                                                                                                \
+        le = c_le.v[e];                                                                                                \
+        ls = c_ls.v[e];                                                                                                \
+        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                    \
+        iv = c_iv.v[e];                                                                                                \
+      }                                                                                                                \
+      /* (k, c-1) holds sweep k at (i-1, j) one step earlier: DPP row_shr:1; c == 0 keeps cW = the row above, in the ring */ \
+      const float t = gs_core<FAST, FAST && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);            \
+      const float v = (FAST && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                             \
+      res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                             \
+      if (e == h) out.x = res; else out.y = res;                                                                       \
+    }                                                                                                                  \
+    ST2(q_wd, (O) + h, out);                                                                                           \
+    const f2u w2 = LD2(q_cW, (O) + 4 + h);                                                                             \
+    const f2u n2 = LD2(q_cN, (O) + 4 + h), e2 = LD2(q_dE, (O) + 4 + h);                                                \
+    nW[h] = w2.x, nW[h + 1] = w2.y;                                                                                    \
+    nN[h] = n2.x, nN[h + 1] = n2.y, nE[h] = e2.x, nE[h + 1] = e2.y;                                                    \
+  }                                                                                                                    \
+  { /* r of the chunk after the next one, into the set just used up */                                                \
+    const F4 t_ = ld4b(rg, o_rv + 4u * (unsigned)((O) + 8));                                                           \
+    cR[0] = t_.v[0], cR[1] = t_.v[1], cR[2] = t_.v[2], cR[3] = t_.v[3];                                                \
+  }
+#define GS3_CHUNK2(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, \
+                   n_ln4)                                                                                              \
+  {                                                                                                                    \
+    if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
+    GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
+  }
+#define GS3_ITER(STEADY)                                                                                               \
+  {                                                                                                                    \
+    if (SYNC == 2) { /* the upper strip must be kFollow steps ahead of everything this iteration touches */           \
+      const int need_ = pbase + tau0 + kFollow;                                                                        \
+      for (int spin_ = 0; seen < need_ && spin_ < (1 << 18); ++spin_) { /* bounded: never a hang */                     \
+        __builtin_amdgcn_s_sleep(1);                                                                                   \
+        seen = *prog;                                                                                                  \
+      }                                                                                                                \
+      asm volatile("" ::: "memory");                                                                                   \
+    }                                                                                                                  \
+    GS3_CHUNK2(STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, \
+               b_ln4)                                                                                                  \
+    if (SYNC == 2) seen = *prog; /* read early: consumed at the top of the next iteration */                          \
+    GS3_CHUNK2(STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls,   \
+               a_iv, a_ln4)                                                                                            \
+    /* opaque to the optimiser: the addresses are NOT re-derived from tau0 (one VALU add per access otherwise) */     \
+    asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
+                 "v_add_u32 %4, 32, %4"                                                                                \
+                 : "+v"(o_rv), "+v"(q_cW), "+v"(q_cN), "+v"(q_dE), "+v"(q_wd));                                        \
+    if (SYNC == 1) { /* published after the iteration's stores */                                                     \
+      asm volatile("" ::: "memory");                                                                                   \
+      if (lane == 0) *prog = pbase + tau0 + 8;                                                                         \
+      asm volatile("" ::: "memory");                                                                                   \
+    }                                                                                                                  \
+  }
+  // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
+  // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
+  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
+  const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
+  int tau0 = 0;
+  for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
+  if (FAST)
+    for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
+  for (; tau0 < steps8; tau0 += 8) GS3_ITER(false)
+  if (tau0 < steps) {
+    if (SYNC == 2) {
+      const int need_ = pbase + tau0 + kFollow;
+      for (int spin_ = 0; seen < need_ && spin_ < (1 << 18); ++spin_) {
+        __builtin_amdgcn_s_sleep(1);
+        seen = *prog;
+      }
+      asm volatile("" ::: "memory");
+    }
+    GS3_CHUNK2(false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
+  }
+  if (SYNC == 1) {  // done: the follower needs no further permission
+    asm volatile("" ::: "memory");
+    if (lane == 0) *prog = pbase + (1 << 20);
+  }
+#undef GS3_ITER
+#undef LD2
+#undef ST2
+#undef GS3_CHUNK2
+#undef GS3_STEPS
+#undef GS_CHUNK
+}
+
 // prolongate(coarse.x) at a (possibly ghost) cell of the fine level (MG.pde:139-152 incl. setBC)
 __device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc, int i, int j, int n_, int m_) {
   const int ci = i < 1 ? 1 : (i > n_ ? n_ : i), cj = j < 1 ? 1 : (j > m_ ? m_ : j);
@@ -843,6 +1044,7 @@ struct UpGeom {
   int NR = kRing;        // rows in the LDS rings (24 for the strip march, H + 6 for the multi-wave smoother)
   bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
   bool update_x = true;  // false: replay that only materialises r
+  float *rglob = nullptr;  // mg_up_smooth2: r after the prolongation increment lives HERE (global), not in an LDS ring
 };
 struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
   F4 r;
@@ -851,6 +1053,7 @@ struct FillIn {  // r of the chunk + the coarse x values its prolongation stenci
 struct ExitIn {  // x of the chunk, the coarse x under it, the two x ghosts a boundary chunk mirrors into
   F4 x;
   float a1, a2, gl, gh;
+  F4 r;  // mg_up_smooth2 with need_r: r of the chunk (from UpGeom::rglob)
 };
 
 __device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, int g, int c4) {
@@ -923,10 +1126,16 @@ __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
   }
+  if (U.rglob) {
+    if (g <= n_) store4u(U.rglob + g * m + j, rv);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    U.rr[sl + e] = rv.v[e];
-    U.dr[sl + e] = dv.v[e];
+    for (int e = 0; e < 4; ++e) U.dr[sl + e] = dv.v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      U.rr[sl + e] = rv.v[e];
+      U.dr[sl + e] = dv.v[e];
+    }
   }
   if (c4 == 0) U.dr[sl - 1] = 0.f;  // ghost columns of d0 read as zero
   if (c4 == CPR - 1) U.dr[sl + 4] = 0.f;
@@ -936,12 +1145,16 @@ __device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, in
   ExitIn in;
   const int kk = g * U.m + 1 + 4 * c4;
   in.a1 = in.a2 = in.gl = in.gh = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) in.r.v[e] = 0.f;
   if (!U.update_x) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) in.x.v[e] = 0.f;
+    if (U.rglob) in.r = load4u(U.rglob + kk);
     return in;
   }
   in.x = load4u(U.F->x + kk);
+  if (U.rglob) in.r = load4u(U.rglob + kk);
   if (HASC) {
     const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
     float a12[2];
@@ -1002,7 +1215,8 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
       const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
       const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
       const float d = d6[1 + e];
-      rn.v[e] = rr[sl + e] - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
+      const float rold = U.rglob ? in.r.v[e] : rr[sl + e];
+      rn.v[e] = rold - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
       const float pr = rn.v[e] * rn.v[e];
       rr_part += (double)pr;
       linf = jmax(linf, jabs(rn.v[e]));
@@ -1294,6 +1508,102 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (mk) pf.mark(PF_INC0);
   }
   __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
+  if (need_r && rmode != 2) {
+    *rr_out = uni((float)block_sum_d(rr_part, sm));
+    *linf_out = uni(block_max_f(linf, sm));
+    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+  }
+}
+
+// mg_up_smooth with TWO STRIPS PER ROUND and two marching waves (levels whose rows are chunks of four columns and at
+// least 64 rows high -- 34 columns wide: the r stream of a lane starts up to 26 floats before column 1 of its row, which
+// must not fall in front of the array): a round fills 32 rows, waves 0 and 1 march the strips I0 and I0+16 (gs_march4: the second follows
+// the first at kFollow steps), then 32 rows leave.  Half the barriers, fills and exits of mg_up_smooth per level and
+// two strips of the ordered sweep in flight.  What makes room for the second strip's rows: r (after the prolongation
+// increment) is written to the level's global `d` scratch array by the fill and streamed from there by the marching
+// lanes and by the exit, so LDS holds one ring of kRing2 rows of d only.  Same arithmetic, same order, same bits.
+__device__ __host__ __forceinline__ int gs2_lds_floats(int m) {
+  return AFC_KPAD + (40 /*kRing2*/ + 2) * ring_pitch(m) + 4 * AFC_KPAD + 32;
+}
+__device__ inline void mg_up_smooth2(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                     float *rr_out, float *linf_out, ProfT &pf, float *xsum_out = nullptr,
+                                     const int rmode = 0) {
+  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
+  const int PW = ring_pitch(m);
+  const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));
+  float *dr = lds + kPad, *zrow = dr + kRing2 * PW + kPad, *dummy = zrow + PW + kPad;
+  // the progress word sits beyond everything a lane past the end of the dummy row can reach (kPad + a chunk)
+  volatile lds_i *prog = (volatile lds_i *)(lds_f *)(dummy + PW + kPad + 16);
+  const int tid = threadIdx.x;
+  const LevelDesc &D = *F.desc;
+  const int mc = Cc.m;
+  double rr_part = 0, xs_part = 0;
+  float linf = 0.f;
+  const int CPR = m_ >> 2;
+  const DescU du = desc_u(D);
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, dr /* unused r ring */, dr, du};
+  U.NR = kRing2;
+  U.store_r = (rmode != 1);
+  U.update_x = (rmode != 2);
+  U.rglob = F.d;
+  const int ngrp = kThreads / CPR, rg = tid / CPR, c4 = tid - rg * CPR;
+  const bool grp_on = rg < ngrp;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  __syncthreads();
+  for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;  // the only LDS words that must hold zeros
+  if (tid == 0) *prog = 0;
+  lds_barrier();
+  int loaded = 0, round = 0;
+  for (int IA = 1; IA - 3 <= n_; IA += 32, ++round) {
+    const int IB = IA + 16;
+    const bool two = (IB - 3 <= n_);          // the round's second strip exists
+    const bool last = (IA + 32 - 3 > n_);      // no further round
+    // ---- fill rows loaded+1 .. hi: r' = r - A prolongate(x_c) to global, d0 = r' * inv into the ring ----
+    const int hi = (two ? IB : IA) + 16;
+    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
+    if (grp_on)
+      for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+        const FillIn in = fill_load(U, HASC, g, c4);
+        fill_apply(U, HASC, g, c4, in, sp_fill);
+      }
+    loaded = hi;
+    __syncthreads();  // the marching lanes read r' from global memory
+    if (mk) pf.mark(PF_UP0);
+    const int pbase = round << 21;
+    if (wave < 2 && (wave == 0 || two)) {
+      const int I0 = wave ? IB : IA;
+      const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
+      __builtin_amdgcn_s_setprio(3);
+      // SYNC: 1 = upper strip with a follower, 2 = follower, 0 = a strip alone
+#define GS4(SY)                                                                     \
+  {                                                                                 \
+    if (special)                                                                    \
+      gs_march4<false, true, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);         \
+    else if (du.zb)                                                                 \
+      gs_march4<true, true, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);          \
+    else                                                                            \
+      gs_march4<true, false, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);         \
+  }
+      if (wave == 1) GS4(2)
+      else if (two) GS4(1)
+      else GS4(0)
+#undef GS4
+      __builtin_amdgcn_s_setprio(0);
+    }
+    lds_barrier();
+    if (mk) pf.mark(PF_GS0);
+    // ---- exit: rows whose d (and d of both row neighbours) is final ----
+    const int e0 = (IA - 4 < 1) ? 1 : IA - 4, e1 = last ? n_ : ((two ? IB : IA) + 11);
+    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
+    if (grp_on)
+      for (int g = e0 + rg; g <= e1; g += ngrp) {
+        const ExitIn in = exit_load(U, HASC, g, c4);
+        exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+      }
+    lds_barrier();  // the next round's fill re-uses ring slots this exit has just read
+    if (mk) pf.mark(PF_INC0);
+  }
+  __syncthreads();
   if (need_r && rmode != 2) {
     *rr_out = uni((float)block_sum_d(rr_part, sm));
     *linf_out = uni(block_max_f(linf, sm));
@@ -1899,20 +2209,6 @@ __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv
   __syncthreads();
 }
 
-// 16-byte access at a 32-bit byte offset from a wave-uniform base: global_* with the base in SGPRs, no 64-bit lane address
-__device__ __forceinline__ F4 ld4b(const float *base, unsigned boff) {
-  F4 r;
-  __builtin_memcpy(&r, (const char *)base + boff, 16);
-  return r;
-}
-__device__ __forceinline__ float ld1b(const float *base, unsigned boff) {
-  float r;
-  __builtin_memcpy(&r, (const char *)base + boff, 4);
-  return r;
-}
-__device__ __forceinline__ void st4b(float *base, unsigned boff, const F4 &v) { __builtin_memcpy((char *)base + boff, &v, 16); }
-__device__ __forceinline__ void st1b(float *base, unsigned boff, float v) { __builtin_memcpy((char *)base + boff, &v, 4); }
-
 constexpr int kHeadNS = 8;                                       // rows in a wave's d ring
 constexpr int kHeadLdsFloats = 4 * (kHeadNS * 132 + 8) + 8;      // head_v3: four rings (m = 130: pitch 132)
 
@@ -2151,13 +2447,22 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2);
-      if (!(AFC_DBG_OF(P) & 4))
+      // two strips per round / two marching waves where the level is big enough and its rings fit the LDS region
+      // two strips per round / two marching waves (mg_up_smooth2): bit-exact, but measured SLOWER than the single march
+      // (DESIGN.md): kept as an experiment of the diagnostic instantiation only (dbg bit 8 switches it on)
+      const bool two_strips = AFC_DIAG && !AFC_RB && uni(P.up2) && ((F.m - 2) & 3) == 0 && (F.n - 2) >= 64 &&
+                              (AFC_DBG_OF(P) & 256);
+      if (two_strips)
+        mg_up_smooth2(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else if (!(AFC_DBG_OF(P) & 4))
         mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else
         mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
         float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
-        if (!(AFC_DBG_OF(P) & 4))
+        if (two_strips)
+          mg_up_smooth2(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        else if (!(AFC_DBG_OF(P) & 4))
           mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   __shared__ afc::ShBcast sh;
   extern __shared__ float lds_dyn[];
   const size_t e = blockIdx.x;
+  // placement experiment (gate value 14): the workgroups of every second group of 128 CU slots leave at once, so that
+  // half the CUs carry four envs each and the other half idles -- against the same number of envs two per CU on all
+  // CUs this separates contention inside a CU from contention for the chip's memory system
+  if (DIAG && P.gate_limit == 14 && (blockIdx.x & 255) >= 128) return;
   if (DIAG && P.stagger_ticks > 0) {  // workgroups b, b+256, b+512, ... tend to share a CU: offset their phases
     const long long t_end = wall_clock64() + (long long)P.stagger_ticks * (long long)((blockIdx.x >> (P.stagger_shift & 15)) % (unsigned)((P.stagger_shift >> 4) + 2));
     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64);

@@ -239,7 +239,8 @@ def _rank_worker(rank, world, port, q):
 
 PATHS = [(4, "all-waves smoother"), (15 << 16, "CU populations taking turns"), (2, "r written back on every V-cycle"),
          (1024, "advection as LDS tiles with workgroup barriers (advdif_v2)"),
-         (2048, "solve head in 14-row blocks with workgroup barriers (mg_down_fused)")]
+         (2048, "solve head in 14-row blocks with workgroup barriers (mg_down_fused)"),
+         (256, "up-legs with two strips per round and two marching waves, r streamed from global memory (mg_up_smooth2)")]
 
 
 def _run_path(envmod, dbg, exact):
@@ -269,7 +270,8 @@ def test_experiment_paths_are_bit_identical_to_the_default(envmod, dbg, what, ex
     r1, u1, v1, p1, h1 = _run_path(envmod, dbg, exact)
     assert h0[1:].sum() > 0  # some solves took more than one V-cycle
     assert np.array_equal(h0, h1), what
-    loose = (dbg == 4 and exact == 0)
+    # ... and the two-strip up-leg hands a thread other rows of the exit, so its partial sums differ the same way
+    loose = (dbg in (4, 256) and exact == 0)
     for (o0, w0, n0), (o1, w1, n1) in zip(r0, r1):
         assert np.array_equal(n0, n1), what
         if loose:
