@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed round-2 line has every field of the contract, its numbers are
+"""The bench line the driver parses: the committed round-3 line has every field of the contract, its numbers are
 consistent with each other, and bench.py's argument parser keeps the contract's flags (CPU only, nothing is launched)."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
         return json.loads(f.read().strip().split("\n")[-1])
 
 
@@ -51,3 +51,25 @@ def test_bench_cli_keeps_the_contract_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_committed_traffic_figure_belongs_to_the_shipped_kernel_sources():
+    """roofline.traffic comes from profiles/r3_hbm_traffic.json, which records the hash of the kernel sources it was
+    measured on: bench.py attaches it only when that hash equals the tree's (a stale figure is refused, not quoted)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    tj = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
+    assert tj["kernel_src_sha16"] == bench.kernel_source_hash()
+    d = _line()
+    assert d["roofline"]["traffic"] == tj["hbm_bytes_per_launch"]
+    assert d["config"]["kernel_src_sha16"] == tj["kernel_src_sha16"] and d["config"]["dbg"] == 0
+
+
+def test_other_baseline_configs_are_named_not_custom():
+    for f, name in (("r3_bench_cfg4.json", "BASELINE.json configs[3]"), ("r3_bench_native.json", "reference-native 384x192")):
+        with open(os.path.join(ROOT, "profiles", f)) as fh:
+            d = json.loads(fh.read().strip().split("\n")[-1])
+        assert d["config"]["workload"].startswith(name) and d["roofline"]["frac"] > 0.2 and d["diverged_envs"] == 0
+    with open(os.path.join(ROOT, "profiles", "r3_bench_perfmode.json")) as fh:
+        d = json.loads(fh.read().strip().split("\n")[-1])
+    assert "PERF MODE" in d["config"]["workload"] and d["config"]["gs_order"].startswith("red-black")
