@@ -427,6 +427,12 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     if (l >= 1) soff += cnt + pad;
   }
   P.Cs = 4 * ((soff + 63) / 64 * 64);
+  {  // the bottom of the V-cycle out of LDS: needs at least two levels there, one level above it, and room
+    const int lb = afc::prod::bottom_first_level(P.lev, P.nlev);
+    P.bottom_lb = (P.impl != 0 && lb >= 2 && lb <= P.nlev - 2 &&
+                   (size_t)afc::prod::bottom_lds_floats(P.lev, P.nlev) * sizeof(float) <= env->lds_bytes) ? lb : 0;
+  }
+
   lx.insert(lx.end(), 128, 0.f);  // tail padding: the strip Gauss-Seidel prefetches a few cells past a row
   ly.insert(ly.end(), 128, 0.f);
   inv.insert(inv.end(), 128, 1.f);

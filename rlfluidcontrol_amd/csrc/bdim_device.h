@@ -108,6 +108,7 @@ struct StepParams {
   int head_v3;         // 1: the barrier-free head of the pressure solve (grids of 128 interior columns)
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
   int up2;             // 1: up-legs with two strips per round and two marching waves (mg_up_smooth2)
+  int bottom_lb;       // first multigrid level of the LDS-resident bottom of the V-cycle (mg_bottom); 0 = none
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
 };

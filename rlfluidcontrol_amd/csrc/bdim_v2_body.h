@@ -2394,6 +2394,127 @@ __device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, 
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The bottom of the V-cycle out of LDS.  Levels from LB on (the first level whose shorter side has at most 16 cells:
+// 32x16 and below on the 16:8 grids, ~700 cells in all) cost next to nothing in arithmetic but, done level by level through
+// global memory, a dozen barrier-separated passes with a round trip each per level -- 200 us of the 1 750 us sim-step
+// at 1024 envs (profiles/r3_level_profile_E1024.txt).  Here r, x, d AND the coefficient arrays of those levels live in
+// LDS for the whole sub-cycle: one cooperative load (coefficients + r of level LB), then the straightforward kernels of
+// bdim_device.h (mg_dinv / mg_increment / mg_restrict / mg_prolong: the reference's whole-array operations, already
+// pinned bit for bit by the impl = 0 tests) on LDS arrays, the four ordered Gauss-Seidel sweeps as pipelined
+// hyperplanes by ONE wave without workgroup barriers (4 sweeps x <= 16 cells per hyperplane = <= 64 lanes; the LDS
+// operations of a wave execute in order), and one store of x of level LB for the up-leg of the level above.
+// ---------------------------------------------------------------------------------------------
+__device__ __host__ __forceinline__ int bottom_first_level(const LevelDesc *lev, int nlev) {
+  for (int l = 1; l < nlev; ++l) {
+    const int a = lev[l].n - 2, b = lev[l].m - 2;
+    if ((a < b ? a : b) <= 16) return l;
+  }
+  return nlev;  // none
+}
+__device__ __host__ __forceinline__ int bottom_lds_floats(const LevelDesc *lev, int nlev) {
+  int f = 16;
+  for (int l = bottom_first_level(lev, nlev); l < nlev; ++l) f += 6 * ((lev[l].n * lev[l].m + 3) & ~3);
+  return f;
+}
+
+// itmx in-place lexicographic Gauss-Seidel sweeps (MG.pde:81-89) as pipelined hyperplanes (mg_gs of bdim_device.h:
+// cell (i,j) of sweep k at step (i-1)+(j-1)+2k), by the calling wave alone: every lane reads its four neighbours,
+// then writes -- within a step no cell depends on another, and what a step reads was written at least one step
+// (one instruction sequence of this same wave) earlier.
+__device__ inline void mg_gs_wave(const Lv &L, int itmx) {
+  const int n_ = L.n - 2, m_ = L.m - 2, m = L.m;
+  const int H = n_ + m_ - 1;
+  const int W = (n_ < m_) ? n_ : m_;
+  const int steps = H + 2 * (itmx - 1);
+  const int w = threadIdx.x & 63;
+  const int kk = w / W, q = w - kk * W;
+  float *d = L.d;
+  for (int tau = 0; tau < steps; ++tau) {
+    const int h = tau - 2 * kk;
+    if (kk < itmx && h >= 0 && h < H) {
+      const int lo = (h - (m_ - 1) > 0) ? h - (m_ - 1) : 0;
+      const int hi = (h < n_ - 1) ? h : n_ - 1;
+      const int ii = lo + q;
+      if (ii <= hi) {
+        const int i = ii + 1, j = h - ii + 1;
+        const int k = i * m + j;
+        d[k] = -(d[k - m] * L.lx[k] + d[k + m] * L.lx[k + m] + d[k - 1] * L.ly[k] + d[k + 1] * L.ly[k + 1] - L.r[k]) *
+               L.inv[k];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // program order kept; the stores of this step are issued
+  }
+}
+
+__device__ inline void mg_bottom(const StepParams &P, size_t e, int LB, float *lds) {
+  const int kc = P.nlev - 1;
+  const int tid = threadIdx.x;
+  float *base = lds + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2);
+  // LDS level l: [r | x | d | lx | ly | inv], each cnt_l floats (rounded up to four)
+  auto lds_level = [&](int l) {
+    int off = 0;
+    for (int q = LB; q < l; ++q) off += 6 * ((P.lev[q].n * P.lev[q].m + 3) & ~3);
+    const int cnt = (P.lev[l].n * P.lev[l].m + 3) & ~3;
+    Lv L;
+    L.n = P.lev[l].n;
+    L.m = P.lev[l].m;
+    float *b0 = base + off;
+    L.r = b0;
+    L.x = b0 + cnt;
+    L.d = b0 + 2 * cnt;
+    L.lx = b0 + 3 * cnt;
+    L.ly = b0 + 4 * cnt;
+    L.inv = b0 + 5 * cnt;
+    L.desc = &P.lev[l];
+    return L;
+  };
+  __syncthreads();  // the region's previous user is done; r of level LB (written by the level above) is visible
+  for (int l = LB; l <= kc; ++l) {  // one cooperative load: the coefficients of every bottom level, r of the first
+    const Lv G_ = make_level(P, e, l), S = lds_level(l);
+    const int cnt = G_.n * G_.m;
+    float *slx = const_cast<float *>(S.lx), *sly = const_cast<float *>(S.ly), *sinv = const_cast<float *>(S.inv);
+    for (int k = tid; k < cnt; k += kThreads) {
+      slx[k] = G_.lx[k];
+      sly[k] = G_.ly[k];
+      sinv[k] = G_.inv[k];
+      S.x[k] = 0.f;  // coarse levels start from x = 0 (MG.pde:56)
+      if (l == LB) {  // the level above stored the interior of its restricted residual; restrict() ends with setBC
+        const int i = k / G_.m, j = k - i * G_.m;
+        S.r[k] = G_.r[clampi(i, 1, G_.n - 2) * G_.m + clampi(j, 1, G_.m - 2)];
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = LB; l < kc; ++l) {  // descending leg (MG.pde:69-70)
+    const Lv F = lds_level(l), Cc = lds_level(l + 1);
+    mg_dinv(F);  // smooth(0)
+    mg_increment(F);
+    mg_restrict(F, Cc);
+  }
+  {  // coarsest level: smooth(its) (MG.pde:73)
+    const Lv Lk = lds_level(kc);
+    mg_dinv(Lk);
+    if (tid < 64) mg_gs_wave(Lk, 4);
+    __syncthreads();
+    mg_increment(Lk);
+  }
+  for (int l = kc - 1; l >= LB; --l) {  // ascending leg (MG.pde:75-76) + the caller's smooth(its)
+    const Lv F = lds_level(l), Cc = lds_level(l + 1);
+    mg_prolong(F, Cc);
+    mg_increment(F);
+    mg_dinv(F);
+    if (tid < 64) mg_gs_wave(F, 4);
+    __syncthreads();
+    mg_increment(F);
+  }
+  {  // x of the first bottom level back to global memory: the up-leg of the level above prolongates from it
+    const Lv G_ = make_level(P, e, LB), S = lds_level(LB);
+    for (int k = tid; k < G_.n * G_.m; k += kThreads) G_.x[k] = S.x[k];
+  }
+  __syncthreads();
+}
+
 // MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
 // (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
@@ -2402,11 +2523,13 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
                                   const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
                                   ProfT &pf, float *lds, bool fused_head = true) {
   const int kc = P.nlev - 1;
+  // levels LB .. kc run out of LDS (mg_bottom) where the host found room for them; LB > kc: level by level as before
+  const int LB = (!AFC_RB && uni(P.bottom_lb) >= 2 && !(AFC_DBG_OF(P) & 128)) ? uni(P.bottom_lb) : kc + 1;
   int iter = 0;
   float linf = 0.f, xsum = 0.f;
   while (iter < P.mg_max_iters) {
     ++iter;
-    for (int l = 0; l < kc; ++l) {  // descending leg of vCycle (MG.pde:69-70)
+    for (int l = 0; l < kc && l < LB; ++l) {  // descending leg of vCycle (MG.pde:69-70)
       const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
       if (l == 0 && iter == 1 && fused_head) {
         if (F.m == 130 && ((F.n - 2) & 7) == 0 && uni(P.head_v3) && !(AFC_DBG_OF(P) & 2048))
@@ -2432,7 +2555,10 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       if (l == 0 && pf.stop == 3) return iter;
     }
     float rr = 0.f;
-    {
+    if (LB <= kc) {
+      mg_bottom(P, e, LB, lds);
+      pf.mark(16 + kc);
+    } else {
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
       if (!(AFC_DBG_OF(P) & 4))
@@ -2441,7 +2567,7 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
         mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
     }
-    for (int l = kc - 1; l >= 0; --l) {
+    for (int l = (LB <= kc ? LB - 1 : kc - 1); l >= 0; --l) {
       if (l == 0 && pf.stop == 4) return iter;
       const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
