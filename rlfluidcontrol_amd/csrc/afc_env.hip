@@ -429,10 +429,31 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.Cs = 4 * ((soff + 63) / 64 * 64);
   {  // the bottom of the V-cycle out of LDS: needs at least two levels there, one level above it, and room
     const int lb = afc::prod::bottom_first_level(P.lev, P.nlev);
-    P.bottom_lb = (P.impl != 0 && lb >= 2 && lb <= P.nlev - 2 &&
+    P.bottom_lb = (P.impl != 0 && lb >= 2 && lb <= P.nlev - 2 && afc::prod::bottom_shape_ok(P.lev, P.nlev) &&
                    (size_t)afc::prod::bottom_lds_floats(P.lev, P.nlev) * sizeof(float) <= env->lds_bytes) ? lb : 0;
   }
 
+  std::vector<float> brec;  // mg_bottom's record table: one 32-byte record per cell of the bottom levels
+  if (P.bottom_lb)
+    for (int l = P.bottom_lb; l < P.nlev; ++l) {
+      const int n = P.lev[l].n, m = P.lev[l].m, off = P.lev[l].coef_off;
+      for (int k = 0; k < afc::prod::bottom_cells4(P.lev[l]); ++k) {
+        float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < n * m) {
+          const int i = k / m, j = k % m;
+          if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+            rec[0] = lx[off + k];
+            rec[1] = lx[off + k + m];
+            rec[2] = ly[off + k];
+            rec[3] = ly[off + k + 1];
+          }
+          rec[4] = inv[off + k];
+        }
+        brec.insert(brec.end(), rec, rec + 8);
+      }
+    }
+  brec.insert(brec.end(), 64, 0.f);
+  if (!rc) rc = dev_upload(env, &P.bottom_rec, brec);
   lx.insert(lx.end(), 128, 0.f);  // tail padding: the strip Gauss-Seidel prefetches a few cells past a row
   ly.insert(ly.end(), 128, 0.f);
   inv.insert(inv.end(), 128, 1.f);

@@ -2398,12 +2398,24 @@ __device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, 
 // The bottom of the V-cycle out of LDS.  Levels from LB on (the first level whose shorter side has at most 16 cells:
 // 32x16 and below on the 16:8 grids, ~700 cells in all) cost next to nothing in arithmetic but, done level by level through
 // global memory, a dozen barrier-separated passes with a round trip each per level -- 200 us of the 1 750 us sim-step
-// at 1024 envs (profiles/r3_level_profile_E1024.txt).  Here r, x, d AND the coefficient arrays of those levels live in
-// LDS for the whole sub-cycle: one cooperative load (coefficients + r of level LB), then the straightforward kernels of
-// bdim_device.h (mg_dinv / mg_increment / mg_restrict / mg_prolong: the reference's whole-array operations, already
-// pinned bit for bit by the impl = 0 tests) on LDS arrays, the four ordered Gauss-Seidel sweeps as pipelined
-// hyperplanes by ONE wave without workgroup barriers (4 sweeps x <= 16 cells per hyperplane = <= 64 lanes; the LDS
-// operations of a wave execute in order), and one store of x of level LB for the up-leg of the level above.
+// at 1024 envs (profiles/r3_level_profile_E1024.txt).  Here everything those levels touch lives in LDS for the whole
+// sub-cycle, as one RECORD of eight floats per cell (ghost cells included):
+//     { lw, le, ls, ln | inv, r, x, d }      lw..ln = the four face coefficients of the cell, gathered by the host
+// The records of all bottom levels are one contiguous table in global memory (StepParams::bottom_rec, shared by all
+// envs, r = x = d = 0) that the workgroup copies into LDS with the LDS-DMA path: one round trip, no registers.
+//
+// The reference's whole-array operations (MG.pde:53-97, 124-152; the straightforward kernels of bdim_device.h are
+// their transcription) are regrouped into passes that form every value with the same operands in the same order:
+//   load    the record table; r of level LB with the setBC clamp the restriction ends with; d = r*inv
+//   down l  B:  x = 0 + d;  r -= A d  (d of out-of-domain neighbours through the setBC mirror)        [smooth(0)]
+//           CA: r_c = restrict(r) (+ setBC clamp), x_c = 0, d_c = r_c*inv_c on the whole coarse array
+//   kc      the four ordered Gauss-Seidel sweeps (bottom_gs_wave)
+//   up l    E:  with X(c) = x_c + d_c formed on the fly (the coarse level's last increment, never stored):
+//               x += X(parent); r -= A prolongate(X); d = r*inv; then the four sweeps
+//   store   x + d of level LB (interior; nothing reads a coarse level's ghost x) for the up-leg of the level above
+// The ghost cells of d keep r_ghost*inv_ghost from the pass that formed r (nothing changes a ghost r afterwards), which
+// is what the reference's d = r.times(inv) puts there before every run of sweeps.  r -= A d of a level's LAST
+// increment is never formed: nothing reads that residual.
 // ---------------------------------------------------------------------------------------------
 __device__ __host__ __forceinline__ int bottom_first_level(const LevelDesc *lev, int nlev) {
   for (int l = 1; l < nlev; ++l) {
@@ -2412,108 +2424,237 @@ __device__ __host__ __forceinline__ int bottom_first_level(const LevelDesc *lev,
   }
   return nlev;  // none
 }
+// the sweeps march down the columns with one lane per column: at most 16 columns, no more columns than rows, and
+// few enough cells (three per thread; the multiply-shift division of the passes is exact below 2048)
+__device__ __host__ __forceinline__ bool bottom_shape_ok(const LevelDesc *lev, int nlev) {
+  for (int l = bottom_first_level(lev, nlev); l < nlev; ++l) {
+    const int a = lev[l].n - 2, b = lev[l].m - 2;
+    if (b > 16 || b > a || b < 1 || lev[l].n * lev[l].m > 3 * kThreads) return false;  // <= 3 cells per thread
+  }
+  return true;
+}
+__device__ __host__ __forceinline__ int bottom_cells4(const LevelDesc &D) { return (D.n * D.m + 3) & ~3; }
 __device__ __host__ __forceinline__ int bottom_lds_floats(const LevelDesc *lev, int nlev) {
   int f = 16;
-  for (int l = bottom_first_level(lev, nlev); l < nlev; ++l) f += 6 * ((lev[l].n * lev[l].m + 3) & ~3);
+  for (int l = bottom_first_level(lev, nlev); l < nlev; ++l) f += 8 * bottom_cells4(lev[l]);
   return f;
 }
 
-// itmx in-place lexicographic Gauss-Seidel sweeps (MG.pde:81-89) as pipelined hyperplanes (mg_gs of bdim_device.h:
-// cell (i,j) of sweep k at step (i-1)+(j-1)+2k), by the calling wave alone: every lane reads its four neighbours,
-// then writes -- within a step no cell depends on another, and what a step reads was written at least one step
-// (one instruction sequence of this same wave) earlier.
-__device__ inline void mg_gs_wave(const Lv &L, int itmx) {
-  const int n_ = L.n - 2, m_ = L.m - 2, m = L.m;
-  const int H = n_ + m_ - 1;
-  const int W = (n_ < m_) ? n_ : m_;
-  const int steps = H + 2 * (itmx - 1);
-  const int w = threadIdx.x & 63;
-  const int kk = w / W, q = w - kk * W;
-  float *d = L.d;
-  for (int tau = 0; tau < steps; ++tau) {
-    const int h = tau - 2 * kk;
-    if (kk < itmx && h >= 0 && h < H) {
-      const int lo = (h - (m_ - 1) > 0) ? h - (m_ - 1) : 0;
-      const int hi = (h < n_ - 1) ? h : n_ - 1;
-      const int ii = lo + q;
-      if (ii <= hi) {
-        const int i = ii + 1, j = h - ii + 1;
-        const int k = i * m + j;
-        d[k] = -(d[k - m] * L.lx[k] + d[k + m] * L.lx[k + m] + d[k - 1] * L.ly[k] + d[k + 1] * L.ly[k + 1] - L.r[k]) *
-               L.inv[k];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // program order kept; the stores of this step are issued
-  }
+struct BLv {      // a bottom level in LDS (everything wave-uniform)
+  int n, m, n_, m_, cnt;
+  unsigned rcp;   // ceil(2^16 / m): k / m == (k * rcp) >> 16 for k < 2048, m <= 18
+  unsigned rec;   // LDS byte address of the records (32 bytes per cell)
+};
+enum { BR_INV = 4, BR_R = 5, BR_X = 6, BR_D = 7 };  // record fields after the four coefficients
+#define B_REC4(L, k) (*(lds_f4 *)(uintptr_t)((L).rec + 32u * (unsigned)(k)))
+#define B_F(L, k, f) (*(lds_f *)(uintptr_t)((L).rec + 32u * (unsigned)(k) + 4u * (f)))
+__device__ __forceinline__ BLv bottom_level(const StepParams &P, int LB, int l, unsigned base) {
+  unsigned off = 0;
+  for (int q = LB; q < l; ++q) off += 32u * (unsigned)((uni(P.lev[q].n) * uni(P.lev[q].m) + 3) & ~3);
+  BLv L;
+  L.n = uni(P.lev[l].n);
+  L.m = uni(P.lev[l].m);
+  L.n_ = L.n - 2;
+  L.m_ = L.m - 2;
+  L.cnt = L.n * L.m;
+  L.rcp = (65536u + (unsigned)L.m - 1u) / (unsigned)L.m;
+  L.rec = base + off;
+  return L;
 }
 
-__device__ inline void mg_bottom(const StepParams &P, size_t e, int LB, float *lds) {
+// Four in-place lexicographic Gauss-Seidel sweeps (MG.pde:81-89) by the calling wave alone, as pipelined hyperplanes:
+// lane (s, c) = sweep s, column c+1 walks DOWN its column, one row per step, sweep s+1 kLagB = 3 steps behind sweep s.
+//   d[i-1][j]  this lane's previous result (the ghost row's d for i = 1)
+//   d[i][j-1]  the previous result of the lane to the left (DPP row_shr:1; column 1 keeps the ghost column's d)
+//   d[i+1][j], d[i][j+1]  what the previous sweep stored two steps ago (the initial d for sweep 0): fetched, with the
+//   cell's record, right after the stores of step t for step t+2 (same wave: LDS operations execute in order), so
+//   no LDS round trip sits on the chain of dependent steps.
+// One wave issues a dependent instruction every ~10 cycles, so the step is written for few instructions: ONE running
+// address per lane (the record left of its cell; the row below is the next step's address), no clamping -- a lane
+// above or below the grid reads whatever is there (reads outside the workgroup's LDS return 0) and stores to a
+// record nobody reads (the ghost corner).
+constexpr int kLagB = 3;
+__device__ inline void bottom_gs_wave(const BLv &L) {
+  const int lane = threadIdx.x & 63, s = lane >> 4, c = lane & 15;
+  const unsigned pitch = 32u * (unsigned)L.m;
+  const unsigned n_ = (unsigned)L.n_;
+  const int steps = L.n_ + L.m_ - 1 + 3 * kLagB;
+  const int i0 = 1 - kLagB * s - c;                                 // the row of this lane at step 0
+  unsigned im1 = (c < L.m_) ? (unsigned)(i0 - 1) : 0x40000000u;     // row - 1: rows 1 .. n_ are the active ones
+  const unsigned dummy = L.rec + 4u * BR_D;                         // d of the ghost corner (0, 0): never read
+  const float g0 = *(lds_f *)(uintptr_t)(L.rec + 32u * (unsigned)(c + 1) + 4u * BR_D);  // d of the ghost row above the column
+#define BG_F(a, o) (*(lds_f *)(uintptr_t)((a) + (o)))
+  struct Ops {
+    f4a cf;
+    float iv, r, dE, dN, dS0;
+  };
+  // operands of the step whose cell is right of record address a; an = the address one row further down
+  auto fetch = [&](unsigned a, unsigned an) {
+    Ops o;
+    o.cf = *(lds_f4 *)(uintptr_t)(a + 32u);
+    const f2u sv = *(const lds_f2 *)(uintptr_t)(a + 32u + 4u * BR_INV);  // (inv, r)
+    o.iv = sv.x;
+    o.r = sv.y;
+    o.dS0 = BG_F(a, 4u * BR_D);
+    o.dN = BG_F(a, 64u + 4u * BR_D);
+    o.dE = BG_F(an, 32u + 4u * BR_D);
+    return o;
+  };
+  unsigned wa = L.rec + 32u * (unsigned)(i0 * L.m + c);  // may wrap below zero (see above)
+  unsigned wb = wa + pitch, nx = wb + pitch;
+  Ops oa = fetch(wa, wb), ob = fetch(wb, nx);
+  // both sets have landed before the loop is entered: its waits are then the steady state's (a fetch two steps old)
+  asm volatile("" : "+v"(oa.cf), "+v"(oa.iv), "+v"(oa.r), "+v"(oa.dE), "+v"(oa.dN), "+v"(oa.dS0));
+  asm volatile("" : "+v"(ob.cf), "+v"(ob.iv), "+v"(ob.r), "+v"(ob.dE), "+v"(ob.dN), "+v"(ob.dS0));
+  float res = 0.f;
+#define BGS_STEP(O, W)                                                                                                \
+  {                                                                                                                   \
+    const float dW = (im1 == 0u) ? g0 : res;                                                                          \
+    const float dS = __builtin_bit_cast(                                                                              \
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, O.dS0), __builtin_bit_cast(int, res), 0x111, 0xf,  \
+                                           0xf, false));                                                              \
+    res = -(dW * O.cf[0] + O.dE * O.cf[1] + dS * O.cf[2] + O.dN * O.cf[3] - O.r) * O.iv; /* MG.pde:84-88 */           \
+    BG_F((im1 < n_) ? W + 32u + 4u * BR_D : dummy, 0u) = res;                                                         \
+    asm volatile("" ::: "memory"); /* the fetch below reads what OTHER lanes have just stored */                      \
+    const unsigned ny = nx + pitch;                                                                                   \
+    O = fetch(nx, ny);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0); /* keep the fetch here, two steps ahead of its use */                          \
+    W = nx;                                                                                                           \
+    nx = ny;                                                                                                          \
+    ++im1;                                                                                                            \
+  }
+  for (int t = 0; t < steps; t += 2) {
+    BGS_STEP(oa, wa)
+    BGS_STEP(ob, wb)
+  }
+#undef BGS_STEP
+#undef BG_F
+}
+
+__device__ inline void mg_bottom(const StepParams &P, size_t e, int LB, float *lds, ProfT &pf) {
   const int kc = P.nlev - 1;
   const int tid = threadIdx.x;
-  float *base = lds + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2);
-  // LDS level l: [r | x | d | lx | ly | inv], each cnt_l floats (rounded up to four)
-  auto lds_level = [&](int l) {
-    int off = 0;
-    for (int q = LB; q < l; ++q) off += 6 * ((P.lev[q].n * P.lev[q].m + 3) & ~3);
-    const int cnt = (P.lev[l].n * P.lev[l].m + 3) & ~3;
-    Lv L;
-    L.n = P.lev[l].n;
-    L.m = P.lev[l].m;
-    float *b0 = base + off;
-    L.r = b0;
-    L.x = b0 + cnt;
-    L.d = b0 + 2 * cnt;
-    L.lx = b0 + 3 * cnt;
-    L.ly = b0 + 4 * cnt;
-    L.inv = b0 + 5 * cnt;
-    L.desc = &P.lev[l];
-    return L;
-  };
+  const unsigned base = (lds_addr(lds) + 15u) & ~15u;
   __syncthreads();  // the region's previous user is done; r of level LB (written by the level above) is visible
-  for (int l = LB; l <= kc; ++l) {  // one cooperative load: the coefficients of every bottom level, r of the first
-    const Lv G_ = make_level(P, e, l), S = lds_level(l);
-    const int cnt = G_.n * G_.m;
-    float *slx = const_cast<float *>(S.lx), *sly = const_cast<float *>(S.ly), *sinv = const_cast<float *>(S.inv);
-    for (int k = tid; k < cnt; k += kThreads) {
-      slx[k] = G_.lx[k];
-      sly[k] = G_.ly[k];
-      sinv[k] = G_.inv[k];
-      S.x[k] = 0.f;  // coarse levels start from x = 0 (MG.pde:56)
-      if (l == LB) {  // the level above stored the interior of its restricted residual; restrict() ends with setBC
-        const int i = k / G_.m, j = k - i * G_.m;
-        S.r[k] = G_.r[clampi(i, 1, G_.n - 2) * G_.m + clampi(j, 1, G_.m - 2)];
+  // ---- load: the record table by LDS-DMA (16 bytes per lane and copy); r of level LB; d = r*inv ----
+  {
+    const BLv S = bottom_level(P, LB, LB, base);
+    const Lv G_ = uni(make_level(P, e, LB));
+    const int per = (S.cnt + kThreads - 1) / kThreads;
+    float rv[3];  // bottom_shape_ok: level LB has at most 34 x 18 cells
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int k = tid + q * kThreads;
+      rv[q] = 0.f;
+      if (q < per && k < S.cnt) {  // the level above stored the interior of its restricted residual; restrict() ends with setBC
+        const int i = (int)(((unsigned)k * S.rcp) >> 16), j = k - i * S.m;
+        rv[q] = G_.r[clampi(i, 1, S.n_) * S.m + clampi(j, 1, S.m_)];
+      }
+    }
+    unsigned chunks = 0;  // 16-byte pieces of the table
+    for (int l = LB; l <= kc; ++l) chunks += 2u * (unsigned)((uni(P.lev[l].n) * uni(P.lev[l].m) + 3) & ~3);
+    const float *tab = uni(G(P.bottom_rec));
+    const unsigned lane = threadIdx.x & 63u, wv = (unsigned)uni((int)(threadIdx.x >> 6));
+    for (unsigned c0 = 64u * wv; c0 < chunks; c0 += 64u * (kThreads / 64)) {
+      if (c0 + lane < chunks) lds_dma16(tab, 16u * (c0 + lane), base + 16u * c0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int k = tid + q * kThreads;
+      if (q < per && k < S.cnt) {
+        const int i = (int)(((unsigned)k * S.rcp) >> 16), j = k - i * S.m;
+        B_F(S, k, BR_D) = rv[q] * B_F(S, k, BR_INV);  // MG.pde:80
+        if ((unsigned)(i - 1) < (unsigned)S.n_ && (unsigned)(j - 1) < (unsigned)S.m_) B_F(S, k, BR_R) = rv[q];
       }
     }
   }
-  __syncthreads();
-  for (int l = LB; l < kc; ++l) {  // descending leg (MG.pde:69-70)
-    const Lv F = lds_level(l), Cc = lds_level(l + 1);
-    mg_dinv(F);  // smooth(0)
-    mg_increment(F);
-    mg_restrict(F, Cc);
+  lds_barrier();
+  pf.mark(24 + LB);  // diagnostics: load | down passes | up passes | sweeps -> down_L<LB>, down_L<LB+1>, up_L<LB>, up_L<LB+1>
+  // ---- descending leg (MG.pde:69-70) ----
+  for (int l = LB; l < kc; ++l) {
+    const BLv F = bottom_level(P, LB, l, base), C = bottom_level(P, LB, l + 1, base);
+    for (int k = tid; k < F.cnt; k += kThreads) {  // B: d.setBC(); increment()  (MG.pde:90-97)
+      const int i = (int)(((unsigned)k * F.rcp) >> 16), j = k - i * F.m;
+      if ((unsigned)(i - 1) < (unsigned)F.n_ && (unsigned)(j - 1) < (unsigned)F.m_) {
+        const f4a cf = B_REC4(F, k);
+        const int iw = (i - 1 < 1) ? 1 : i - 1, ie = (i + 1 > F.n_) ? F.n_ : i + 1;
+        const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > F.m_) ? F.m_ : j + 1;
+        const float dc = B_F(F, k, BR_D), dw = B_F(F, iw * F.m + j, BR_D), de = B_F(F, ie * F.m + j, BR_D),
+                    ds = B_F(F, i * F.m + js, BR_D), dn = B_F(F, i * F.m + jn, BR_D);
+        const float diag = -(cf[0] + cf[1] + cf[2] + cf[3]);  // PoissonMatrix.pde:45-48
+        const float ad = dc * diag + dw * cf[0] + de * cf[1] + ds * cf[2] + dn * cf[3];  // PoissonMatrix.pde:57-61
+        B_F(F, k, BR_R) = B_F(F, k, BR_R) - ad;
+        B_F(F, k, BR_X) = 0.f + dc;
+      }
+    }
+    lds_barrier();
+    for (int k = tid; k < C.cnt; k += kThreads) {  // CA: restrict + setBC (MG.pde:124-137); d = r*inv (MG.pde:80)
+      const int i = (int)(((unsigned)k * C.rcp) >> 16), j = k - i * C.m;
+      const int ci = clampi(i, 1, C.n_), cj = clampi(j, 1, C.m_);
+      const int kf = ((ci - 1) * 2 + 1) * F.m + (cj - 1) * 2 + 1;
+      const float rc = B_F(F, kf, BR_R) + B_F(F, kf + 1, BR_R) + B_F(F, kf + F.m, BR_R) + B_F(F, kf + F.m + 1, BR_R);
+      B_F(C, k, BR_D) = rc * B_F(C, k, BR_INV);
+      if (ci == i && cj == j) {
+        B_F(C, k, BR_R) = rc;
+        B_F(C, k, BR_X) = 0.f;
+      }
+    }
+    lds_barrier();
   }
-  {  // coarsest level: smooth(its) (MG.pde:73)
-    const Lv Lk = lds_level(kc);
-    mg_dinv(Lk);
-    if (tid < 64) mg_gs_wave(Lk, 4);
-    __syncthreads();
-    mg_increment(Lk);
+  pf.mark(24 + LB + 1);
+  // ---- coarsest level: smooth(its) (MG.pde:73); ascending leg (MG.pde:75-76) + the caller's smooth(its) ----
+  for (int l = kc; l >= LB; --l) {
+    const BLv F = bottom_level(P, LB, l, base);
+    if (l < kc) {
+      const BLv C = bottom_level(P, LB, l + 1, base);
+      for (int k = tid; k < F.cnt; k += kThreads) {  // E
+        const int i = (int)(((unsigned)k * F.rcp) >> 16), j = k - i * F.m;
+        if ((unsigned)(i - 1) < (unsigned)F.n_ && (unsigned)(j - 1) < (unsigned)F.m_) {
+          const int iw = (i - 1 < 1) ? 1 : i - 1, ie = (i + 1 > F.n_) ? F.n_ : i + 1;
+          const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > F.m_) ? F.m_ : j + 1;
+          // X at the parents of the cell and of its four (clamped) neighbours: MG.pde:139-152 after MG.pde:95
+          const int pi = ((i - 1) >> 1) + 1, pj = ((j - 1) >> 1) + 1;
+          const int pw = ((iw - 1) >> 1) + 1, pe = ((ie - 1) >> 1) + 1, ps = ((js - 1) >> 1) + 1, pn = ((jn - 1) >> 1) + 1;
+          const int kcC = pi * C.m + pj, kw = pw * C.m + pj, ke = pe * C.m + pj, ks = pi * C.m + ps, kn = pi * C.m + pn;
+          const float xc = B_F(C, kcC, BR_X) + B_F(C, kcC, BR_D), xw = B_F(C, kw, BR_X) + B_F(C, kw, BR_D),
+                      xe = B_F(C, ke, BR_X) + B_F(C, ke, BR_D), xs = B_F(C, ks, BR_X) + B_F(C, ks, BR_D),
+                      xn = B_F(C, kn, BR_X) + B_F(C, kn, BR_D);
+          const f4a cf = B_REC4(F, k);
+          const float iv = B_F(F, k, BR_INV), ro = B_F(F, k, BR_R), xo = B_F(F, k, BR_X);
+          const float diag = -(cf[0] + cf[1] + cf[2] + cf[3]);
+          const float ad = xc * diag + xw * cf[0] + xe * cf[1] + xs * cf[2] + xn * cf[3];
+          const float rn = ro - ad;
+          B_F(F, k, BR_R) = rn;
+          B_F(F, k, BR_X) = xo + xc;
+          B_F(F, k, BR_D) = rn * iv;  // MG.pde:80
+        }
+      }
+      lds_barrier();
+      pf.mark(16 + LB);
+    }
+    if (tid < 64) {
+      __builtin_amdgcn_s_setprio(3);  // a serial chain, like the march
+      bottom_gs_wave(F);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    lds_barrier();
+    pf.mark(16 + LB + 1);
   }
-  for (int l = kc - 1; l >= LB; --l) {  // ascending leg (MG.pde:75-76) + the caller's smooth(its)
-    const Lv F = lds_level(l), Cc = lds_level(l + 1);
-    mg_prolong(F, Cc);
-    mg_increment(F);
-    mg_dinv(F);
-    if (tid < 64) mg_gs_wave(F, 4);
-    __syncthreads();
-    mg_increment(F);
-  }
-  {  // x of the first bottom level back to global memory: the up-leg of the level above prolongates from it
-    const Lv G_ = make_level(P, e, LB), S = lds_level(LB);
-    for (int k = tid; k < G_.n * G_.m; k += kThreads) G_.x[k] = S.x[k];
+  {  // x + d of the first bottom level to global memory: the up-leg of the level above prolongates from it
+    const Lv G_ = uni(make_level(P, e, LB));
+    const BLv S = bottom_level(P, LB, LB, base);
+    for (int k = tid; k < S.cnt; k += kThreads) {
+      const int i = (int)(((unsigned)k * S.rcp) >> 16), j = k - i * S.m;
+      if ((unsigned)(i - 1) < (unsigned)S.n_ && (unsigned)(j - 1) < (unsigned)S.m_)
+        G_.x[k] = B_F(S, k, BR_X) + B_F(S, k, BR_D);
+    }
   }
   __syncthreads();
 }
+#undef B_REC4
+#undef B_F
 
 // MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
@@ -2556,7 +2697,7 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
     }
     float rr = 0.f;
     if (LB <= kc) {
-      mg_bottom(P, e, LB, lds);
+      mg_bottom(P, e, LB, lds, pf);
       pf.mark(16 + kc);
     } else {
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
