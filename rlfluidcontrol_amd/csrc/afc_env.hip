@@ -371,6 +371,15 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   UP(band_x); UP(band_y);
   P.nband_x = (int)sf.band_x.size();
   P.nband_y = (int)sf.band_y.size();
+  {  // wall columns folded into the row stores: the forcing band (and the cells it reads) must stay clear of the walls
+    bool clear = true;
+    for (const std::vector<int> *b : {&sf.band_x, &sf.band_y})
+      for (int k : *b) {
+        const int i = k / sf.m, j = k % sf.m;
+        if (i < 3 || i > sf.n - 4 || j < 3 || j > sf.m - 4) clear = false;
+      }
+    P.bc_fold = (P.impl != 0 && clear && sf.m <= afc::kRowCap) ? 1 : 0;
+  }
 #undef UP
   // multigrid hierarchy, all levels concatenated
   std::vector<float> lx, ly, inv;

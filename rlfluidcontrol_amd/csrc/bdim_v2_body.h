@@ -331,7 +331,6 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
 #define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
           const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
           ccv[e] = cc;
-          if (xdbg & 16) continue;
           if (ii == 0) {
             const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});  // x: x[i-1][j]+x[i][j]; y: x[i][j-1]+x[i][j]
             fE2[e] = uo * quick_face2(XY(i - 2, j), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);  // = this row's west face
@@ -359,11 +358,6 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         for (int e = 0; e < C; ++e) {
           const int j = j0 + e;
           if (j > m - 2) break;
-          if (xdbg & 16) {
-            oxv[e] = ccv[e].x + bxv[e];
-            oyv[e] = ccv[e].y + byv[e];
-            continue;
-          }
           const f2 fW = fE2[e], fS = (e == 0) ? fSw : fNn[e > 0 ? e - 1 : 0];
           const f2 adv = ((fW - fEn[e]) + (fS - fNn[e]));
           const f2 o = (adv + nu * difv[e]) * dt + f2{bxv[e], byv[e]};              // :174-175
@@ -371,9 +365,7 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           oyv[e] = o.y;
           fE2[e] = fEn[e];
         }
-        if (xdbg & 32) {
-          if (oxv[0] == 12345.678f) dx[i * m + j0] = oyv[0];  // keeps the values live, never taken
-        } else if (full) {
+        if (full) {
           __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
           __builtin_memcpy(dy + i * m + j0, oyv, sizeof(float) * C);
         } else {
@@ -395,7 +387,10 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
 // s_waitcnt vmcnt(N) with the largest even immediate N <= K (K wave-uniform): at most N of the wave's youngest
 // vector-memory operations may still be outstanding afterwards.
 __device__ __forceinline__ void wait_vm_le(int K) {
-  if (K >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  if (K >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (K >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  else if (K >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (K >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else if (K >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if (K >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   else if (K >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -442,8 +437,12 @@ __device__ __forceinline__ unsigned lane_fresh() {
 template <int C>
 __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
-                                 float *__restrict__ dy, float *lds) {
+                                 float *__restrict__ dy, float *lds, const bool fold) {
+  // fold: every row is stored WITH the wall columns setBC would give it (Field.pde:217-224: u.x mirrors the adjacent
+  // interior cell; u.y[.][0] = old u.y[.][1], then u.y[.][1] = u.y[.][m-1] = 0) by its first and last lane -- two
+  // more store instructions per row -- so that what is left of setBC is whole-row work (setbc_rows)
   constexpr int m = 64 * C + 2, LQ = (m + 3) >> 2, PR = 4 * LQ, NS = kAdvNS;
+  const int ST = fold ? 4 : 2;  // store instructions per row iteration
   constexpr unsigned PRB = PR * 4u;              // bytes per ring row
   constexpr int YO = NS * PR;                    // floats from a row of the x ring to the same row of the y ring
   constexpr int BO = 2 * NS * PR;                // floats from the x ring to the base rows: [buf][x|y]
@@ -492,12 +491,12 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         // stores (row j); the first iteration issues its src copies last (row i-2 is still read by its west faces).
         int K;
         if (t >= 3) {  // the copies of row i+2 were issued in iteration i-3: followed by its stores unless that was the first
-          K = (t > 3) ? 2 : 0;
-          for (int jj = i - 2; jj <= i; ++jj) K += ((jj < i_last) ? nb : 0) + ((jj + 5 <= r_hi) ? 2 : 0) + ((jj < i) ? 2 : 0);
+          K = (t > 3) ? ST : 0;
+          for (int jj = i - 2; jj <= i; ++jj) K += ((jj < i_last) ? nb : 0) + ((jj + 5 <= r_hi) ? 2 : 0) + ((jj < i) ? ST : 0);
         } else {  // ... or by the prologue: rows first-2 .. first+4, then base row first; whole iterations follow
           // (>= 8 rows per wave, so every base / src copy of the first three iterations exists)
           K = 2 * (2 - t) + nb + nb + (t > 0 ? 2 : 0);  // rest of the prologue, this iteration's copies
-          K += t * (nb + 4);                            // earlier iterations
+          K += t * (nb + 2 + ST);                       // earlier iterations
         }
         wait_vm_le(K);
       }
@@ -546,7 +545,7 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
       if (nb) {
         // base row i: copied in iteration i-1 (in front of that iteration's src copies and stores, and of this
         // iteration's copies) or by the prologue
-        wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + 2 : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
+        wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + ST : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
         const lds_f *bb = (const lds_f *)(uintptr_t)(lo + (unsigned)(2 * NS + 2 * (i & 1)) * PRB);
 #pragma unroll
         for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
@@ -564,6 +563,16 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         fE2[e] = fEn[e];
       }
       const unsigned ob = 4u * (unsigned)(i * m + j0);  // byte offset of the lane's cells of row i (32-bit: SGPR base + offset)
+      if (fold) {
+        const unsigned ln_ = lane_fresh();
+        if (ln_ == 0u || ln_ == 63u) {  // both lanes exist in every wave: always two store instructions
+          const bool first = (ln_ == 0u);
+          const unsigned gb = 4u * (unsigned)(i * m + (first ? 0 : m - 1));
+          st1b(dx, gb, first ? oxv[0] : oxv[C - 1]);
+          st1b(dy, gb, first ? oyv[0] : 0.f);
+        }
+        if (ln_ == 0u) oyv[0] = 0.f;
+      }
       __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
       __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
       asm volatile("" ::: "memory");
@@ -2745,6 +2754,39 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
   return iter;
 }
 
+// What is left of u.setBC() (Field.pde:204-224 as transcribed by setbc_vel) once every row 1 .. n-2 carries its wall
+// columns (the folded stores of advdif_v3 / project_tail_v2): the inflow / outflow rows.  Row 0 and row n-1 become
+// copies of the folded rows 1 and n-2 -- the same values setbc_vel's column pass leaves in them --, u.x of row 1
+// becomes the inflow value 1, and the interior of the last row of u.x gets the flux correction 1 - mean(outflow).
+// No strided column access is left: the column pass of setbc_vel touched one 64-byte line per row, side and
+// component to move four floats.
+__device__ inline void setbc_rows(const StepParams &P, float *ux, float *uy, float *rowbuf) {
+  __shared__ float s_mean2;
+  const int n = uni(P.n), m = uni(P.m);
+  for (int j = threadIdx.x; j < m; j += kThreads) {
+    ux[j] = ux[m + j];
+    const float o = ux[(n - 2) * m + j];
+    rowbuf[j] = o;
+    ux[m + j] = 1.f;
+    uy[j] = uy[m + j];
+    uy[(n - 1) * m + j] = uy[(n - 2) * m + j];
+  }
+  lds_barrier();
+  if (threadIdx.x == 0) {  // Field.pde:302-318 order
+    float s = 0;
+    for (int j = 1; j < m - 1; ++j) s += rowbuf[j];
+    s /= (float)(m - 2);
+    s_mean2 = s;
+  }
+  lds_barrier();
+  const float corr = 1.f - s_mean2;
+  for (int j = threadIdx.x; j < m; j += kThreads) {
+    const float o = rowbuf[j];
+    ux[(n - 1) * m + j] = (j >= 1 && j <= m - 2) ? o + corr : o;
+  }
+  __syncthreads();
+}
+
 // Tail of u.project (VectorField.pde:136-140) [+ the Heun average of BDIM.update2, BDIM.pde:95-96]:
 //   p' = p + s (s = -sum(p)/N);  u -= c * grad p';  u.setBC();  [A = (u + us)/2]
 // p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
@@ -2753,7 +2795,7 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
 __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, float *lds, const float *__restrict__ p,
                                        float shift, float *vx,
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
-                                       float *ax, float *ay) {
+                                       float *ax, float *ay, const bool fold) {
   const int n = uni(P.n), m = uni(P.m), n_ = n - 2, m_ = m - 2, CPR = m_ >> 2;
   const int sp0 = uni(P.lev[0].sp_i0), sp1 = uni(P.lev[0].sp_i1);
   const float cu = uni(P.lev[0].cu);
@@ -2794,8 +2836,23 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
     // A are formed from registers right here).  Only rows 1 and n-2 are still read: by setBC's row copies and outflow
     // mean and by the 4-row fix-up below.
     if (!HEUN || g == 1 || g == n_) {
-      store4u(vx + k, un);
-      store4u(vy + k, vn);
+      if (fold) {  // the row with the wall columns setBC gives it (see advdif_v3); setbc_rows does the rest
+        if (c4 == 0) {
+          vx[k - 1] = un.v[0];
+          vy[k - 1] = vn.v[0];
+        }
+        if (c4 == CPR - 1) {
+          vx[k + 4] = un.v[3];
+          vy[k + 4] = 0.f;
+        }
+        F4 vs = vn;
+        if (c4 == 0) vs.v[0] = 0.f;
+        store4u(vx + k, un);
+        store4u(vy + k, vs);
+      } else {
+        store4u(vx + k, un);
+        store4u(vy + k, vn);
+      }
     }
     if (HEUN) {  // cells on the rows setBC rewrites (0, 1, n-2, n-1) are redone below
       const F4 b4 = load4u(ox + k), d4 = load4u(oy + k);
@@ -2821,7 +2878,10 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
     }
   }
   __syncthreads();
-  setbc_vel(P, vx, vy, lds);
+  if (fold)
+    setbc_rows(P, vx, vy, lds);
+  else
+    setbc_vel(P, vx, vy, lds);
   if (HEUN) {  // whole rows touched by setBC's row part or by its mean correction: 0, 1, n-2, n-1
     for (int q = threadIdx.x; q < 4 * m; q += kThreads) {
       const int rsel = q / m, j = q - rsel * m;
@@ -2850,7 +2910,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
   const float shift = uni(-1 * psum / (float)((P.n - 2) * (P.m - 2)));  // VectorField.pde:136
-  project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay);
+  project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay, uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u));
   *shift_io = shift;
   pf.mark(PF_PROJECT);
   return iters;
@@ -2921,15 +2981,19 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     float *dx = uni(half ? Cx : Bx), *dy = uni(half ? Cy : By);
     const float *pin = uni(half ? p1 : p0);
     float *pout = uni(half ? p0 : p1);
+    const bool fold = adv3_ok && uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (adv3_ok)
-      advdif_v3<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+      advdif_v3<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     else
       advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
     pf.mark(PF_ADVDIF);
     if (pf.stop == 1 + 8 * half) return;
     forcing_band(P, dx, dy, lds, dphi1, dphi2);
     pf.mark(PF_FORCING);
-    setbc_vel(P, dx, dy, lds);
+    if (fold)
+      setbc_rows(P, dx, dy, lds);
+    else
+      setbc_vel(P, dx, dy, lds);
     pf.mark(PF_SETBC);
     if (pf.stop == 2 + 8 * half) return;
     float l;
