@@ -224,10 +224,11 @@ __device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, l
 template <int C>
 __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
-                                 float *__restrict__ dy, float *lds) {
+                                 float *__restrict__ dy, float *lds, const bool fold = false) {
+  // fold: rows are stored with the wall columns setBC gives them (see advdif_v3)
   const int n = uni(P.n), m = uni(P.m), N = uni(P.N);
   const int R = uni(P.adv_rows), TR = R + 4;
-  // diagnostics: 16 = no stencil arithmetic, 32 = no global stores, 64 = no tile loads, 512 = tiles staged through registers
+  // diagnostics: 64 = no tile loads, 512 = tiles staged through registers
   const int xdbg = uni(AFC_DBG_OF(P));
   // tiles on 16-byte boundaries (the LDS-DMA copies below write 16 bytes per lane); TR*m + 4 floats apart, a multiple
   // of 16 bytes whenever TR*m is a multiple of 4
@@ -364,6 +365,22 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
           oxv[e] = o.x;
           oyv[e] = o.y;
           fE2[e] = fEn[e];
+        }
+        if (fold) {  // Field.pde:217-224: u.x mirrors the adjacent interior cell; u.y[.][0] = old u.y[.][1], u.y[.][1] = u.y[.][m-1] = 0
+          if (j0 == 1) {
+            dx[i * m] = oxv[0];
+            dy[i * m] = oyv[0];
+            oyv[0] = 0.f;
+          }
+          const int el = m - 2 - j0;  // the lane that owns column m-2
+          if (el >= 0 && el < C) {
+            float last = oxv[0];
+#pragma unroll
+            for (int e = 1; e < C; ++e)
+              if (e <= el) last = oxv[e];
+            dx[i * m + m - 1] = last;
+            dy[i * m + m - 1] = 0.f;
+          }
         }
         if (full) {
           __builtin_memcpy(dx + i * m + j0, oxv, sizeof(float) * C);
@@ -2981,11 +2998,11 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     float *dx = uni(half ? Cx : Bx), *dy = uni(half ? Cy : By);
     const float *pin = uni(half ? p1 : p0);
     float *pout = uni(half ? p0 : p1);
-    const bool fold = adv3_ok && uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
+    const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (adv3_ok)
       advdif_v3<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     else
-      advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds);
+      advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     pf.mark(PF_ADVDIF);
     if (pf.stop == 1 + 8 * half) return;
     forcing_band(P, dx, dy, lds, dphi1, dphi2);
