@@ -31,6 +31,9 @@ DEFAULT_INIT = {(16, 100): os.path.join(GOLDEN, "wake_res16_re100.npz"),
                 (32, 400): os.path.join(GOLDEN, "wake_res32_re400.npz"),
                 (24, 500): os.path.join(GOLDEN, "init_bdim_res24.npz")}
 # BASELINE.json workloads by (res, Re, envs per GPU)
+# HBM traffic per launch measured with rocprofv3 --pmc on exactly these kernel sources (tools/pmc_traffic.py), by workload
+TRAFFIC_FILES = {(16, 100, 1024): "r4_hbm_traffic.json", (32, 400, 1024): "r4_hbm_traffic_cfg4.json",
+                 (24, 500, 1024): "r4_hbm_traffic_native.json"}
 WORKLOADS = {(16, 100, 1024): "BASELINE.json configs[1]",
              (32, 400, 1024): "BASELINE.json configs[3]",
              (24, 500, 1024): "reference-native 384x192 Re500 (init.bdim)"}
@@ -291,10 +294,19 @@ def main():
     sync()
     g.mg_histogram(clear=True)
 
-    # device-to-device copy ceiling of THIS box, measured in the same run (1 GiB float4 copy, read + write bytes)
-    copy_bw = None
+    # device-to-device copy ceiling of THIS box, measured in the same run: the library's hand-written 16-byte-per-lane
+    # copy kernel (1 GiB, 2048 workgroups x 256 threads; afc_measure_copy_rate) is the hard ceiling fractions are
+    # quoted against; torch's Tensor.copy_ of the same size (a softer figure) is reported beside it
+    copy_bw = torch_copy_bw = None
     if rank == 0 and not dry:
+        import ctypes
         nb = 1 << 30
+        gbs = ctypes.c_float(0.0)
+        try:
+            if envmod.load_library().afc_measure_copy_rate(local_rank, nb, 5, ctypes.byref(gbs)) == 0:
+                copy_bw = float(gbs.value) * 1e9
+        except AttributeError:  # an older build under tools/ab.sh
+            pass
         a = torch.empty(nb // 4, dtype=torch.float32, device=dev).normal_()
         b = torch.empty_like(a)
         best = 1e9
@@ -305,7 +317,7 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e-3)
-        copy_bw = 2.0 * nb / best
+        torch_copy_bw = 2.0 * nb / best
         del a, b
         torch.cuda.empty_cache()
 
@@ -383,19 +395,22 @@ def main():
                          "kernel": "k_agent_step", "avg_launch_ms": round(1e3 * avg_kern_s, 3),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * cells * sim_per_launch,
                          "copy_ceiling_measured_GBs": round(copy_bw / 1e9, 1) if copy_bw else None,
-                         "frac_of_measured_copy_ceiling": round(achieved / copy_bw, 5) if copy_bw else None},
+                         "frac_of_measured_copy_ceiling": round(achieved / copy_bw, 5) if copy_bw else None,
+                         "copy_ceiling_kernel": "afc_measure_copy_rate: float4 copy, 1 GiB, 2048 x 256 threads",
+                         "torch_copy_GBs": round(torch_copy_bw / 1e9, 1) if torch_copy_bw else None},
         }
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be driven from inside
         # this process): attached only for the exact workload AND the exact kernel sources they were taken on
-        tpath = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
-        if os.path.exists(tpath) and std and not dry:
+        tname = TRAFFIC_FILES.get((args.res, args.reynolds, E))
+        tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+        if tpath and os.path.exists(tpath) and args.gs_mode == 0 and not dry:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_src_sha16") == kernel_source_hash():
                     line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = "profiles/r3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources)"
+                    line["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources)" % tname
                 else:
-                    line["roofline"]["traffic_source"] = "none: profiles/r3_hbm_traffic.json was measured on other kernel sources (%s)" % tj.get("kernel_src_sha16")
+                    line["roofline"]["traffic_source"] = "none: profiles/%s was measured on other kernel sources (%s)" % (tname, tj.get("kernel_src_sha16"))
             except Exception:
                 pass
         if (args.res, args.reynolds) == (32, 400):

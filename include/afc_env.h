@@ -192,13 +192,23 @@ int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count);
 
 /* --- unit-level device entry points (parity tests drive single operators through the same
  * kernels the step uses; all pointers HOST, reference layout) --- */
-/* VectorField.AdvDif (VectorField.pde:170-179) on env 0's geometry: (fx,fy) in/out */
+/* VectorField.AdvDif (VectorField.pde:170-179) on env 0's geometry: (fx,fy) in/out.  Passing u0x == fx and u0y == fy
+ * (the same arrays) is BDIM.update's u0 = u (BDIM.pde:82-84) and runs the predictor's form of the pass. */
 int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const float *u0y);
 /* MGsolver(itmx, PoissonMatrix(c), x, b) (MG.pde:30-38) with the env's own coefficient
  * hierarchy: x in/out, returns iterations in *iters */
 int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, float *resid_linf);
+/* VectorField.project(c, p) (VectorField.pde:130-143) with the env's own c = del*dt: p = MGsolver(20, PoissonMatrix(c),
+ * p, div u); p -= mean(p); u -= c*grad p; u.setBC().  ux, uy, p in/out.  Runs the fused projection of a half-step
+ * (solve head, coarse legs, up-legs, projection tail) exactly as the step dispatches it; impl 2 only. */
+int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters, float *resid_linf);
 /* Field.setBC of the velocity pair (Field.pde:209-234; u.x has gradientExit) */
 int afc_op_setbc_u(afc_env *env, float *ux, float *uy);
+
+/* Measurement helper, no counterpart in the reference: the device-to-device copy rate of the box, bench.py's
+ * "copy ceiling" -- a hand-written 16-byte-per-lane copy of `bytes` bytes (2048 workgroups x 256 threads, grid stride),
+ * best of `reps` passes; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
+int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s);
 
 #ifdef __cplusplus
 }

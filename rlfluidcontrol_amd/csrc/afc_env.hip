@@ -129,6 +129,13 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   __shared__ double sm[afc::kThreads];
   afc::phase_setbc_u(P, 0, sm);
 }
+
+// Measurement helper (bench.py's copy ceiling): a plain 16-byte-per-lane device-to-device copy, 2048 workgroups of 256
+// threads walking the buffer with a grid stride -- the hard ceiling a streaming pass of this shape can reach on the box.
+__global__ __launch_bounds__(256) void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+}
 }  // namespace
 
 // ---------------- host side ----------------
@@ -344,25 +351,31 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)
     const size_t mw_budget = (36 * 1024 + 512) / sizeof(float);
     if (fl < mw_budget) fl = mw_budget;
-    // advdif_v3's rings (4 waves x (2 x 7 + 4) rows): may take the region up to what still leaves four workgroups per
-    // CU (160 KB / 4 = 40960 B per workgroup, ~2.3 KB of it static)
-    {
-      const int m_ = sf.m - 2, cplv = (m_ + 63) / 64;
-      const size_t a3 = (size_t)afc::prod::adv3_lds_floats(cplv);
-      if (m_ == 64 * cplv && a3 > fl && a3 * sizeof(float) + 2560 <= 40960) fl = a3;
-    }
+    // advdif_v3's rings (4 waves x (2 x 7 + 4) rows of one column tile): may take the region up to what still leaves
+    // four workgroups per CU (160 KB / 4 = 40960 B per workgroup, ~2.3 KB of it static).  Grids of 64 or 128 interior
+    // columns are one tile wide (C = 1, 2 cells per lane); 192 and 256 columns are two tiles of 96 / 128 (C = 2)
+    const int m_ = sf.m - 2, n_ = sf.n - 2, cplv = (m_ + 63) / 64, ctile = cplv > 2 ? 2 : cplv;
+    const bool one_tile = (m_ == 64 * ctile), two_tiles = (cplv > 2 && (m_ & 3) == 0 && m_ / 2 <= 64 * ctile);
+    const size_t a3 = (size_t)afc::prod::adv3_lds_floats(ctile);
+    if ((one_tile || two_tiles) && a3 > fl && a3 * sizeof(float) + 2560 <= 40960) fl = a3;
     env->lds_bytes = (P.impl == 0) ? 0 : sizeof(float) * fl;
-    // advdif_v3 (one barrier-free row pipeline per wave): grids of exactly 64*CPL interior columns whose rings fit the
-    // LDS region, >= 8 rows per wave
+    // advdif_v3 (one barrier-free row pipeline per wave): the rings fit the LDS region, >= 8 rows per wave
     P.adv_ns = 0;
-    const int m_ = sf.m - 2, n_ = sf.n - 2, cplv = (m_ + 63) / 64;
-    if (P.impl != 0 && m_ == 64 * cplv && (size_t)afc::prod::adv3_lds_floats(cplv) <= fl && (n_ + 3) / 4 >= 8)
-      P.adv_ns = afc::prod::kAdvNS;
+    const int rows_per_wave = one_tile ? (n_ + 3) / 4 : (n_ + 1) / 2;
+    if (P.impl != 0 && (one_tile || two_tiles) && a3 <= fl && rows_per_wave >= 8) P.adv_ns = afc::prod::kAdvNS;
   }
 
   P.up2 = (P.impl != 0 && (size_t)afc::prod::gs2_lds_floats(sf.m) * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   P.head_v3 = (P.impl != 0 && sf.m == 130 && ((sf.n - 2) & 7) == 0 &&
                (size_t)afc::prod::kHeadLdsFloats * sizeof(float) <= env->lds_bytes) ? 1 : 0;
+  P.down_v3 = 0;
+  if (P.impl != 0) {  // down_v3c: the rings of every level it would serve must fit the region
+    P.down_v3 = 1;
+    for (size_t l = 1; l < sf.levels.size(); ++l)
+      if (afc::prod::down3_shape_ok(sf.levels[l].n, sf.levels[l].m) &&
+          (size_t)afc::prod::down3_lds_floats(sf.levels[l].m) * sizeof(float) > env->lds_bytes)
+        P.down_v3 = 0;
+  }
   int rc = AFC_OK;
 #define UP(field) if (!rc) rc = dev_upload(env, &P.field, sf.field)
   UP(delx); UP(dely); UP(del1x); UP(del1y); UP(wnxx); UP(wnxy); UP(wnyx); UP(wnyy); UP(cx); UP(cy);
@@ -1044,10 +1057,12 @@ int afc_op_advdif(afc_env *env, float *fx, float *fy, const float *u0x, const fl
   HIP_TRY(hipMemcpy(G(P.uy), fy, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0x), u0x, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(G(P.u0y), u0y, bytes, hipMemcpyHostToDevice));
+  // u0 passed as the very arrays of F: BDIM.update's u0 = u (BDIM.pde:82-84), the predictor's form of the pass
+  const int same = (u0x == fx && u0y == fy) ? 1 : 0;
   if (need_diag(env) || P.impl == 0)
-    afc::launch_op_advdif_diag(env->lds_bytes, env->stream, P);
+    afc::launch_op_advdif_diag(env->lds_bytes, env->stream, P, same);
   else
-    afc::launch_op_advdif_prod(env->lds_bytes, env->stream, P);
+    afc::launch_op_advdif_prod(env->lds_bytes, env->stream, P, same);
   int rc = launch_check("k_op_advdif");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
@@ -1071,6 +1086,47 @@ int afc_op_setbc_u(afc_env *env, float *ux, float *uy) {
   HIP_TRY(hipStreamSynchronize(env->stream));
   HIP_TRY(hipMemcpy(ux, G(P.ux), bytes, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(uy, G(P.uy), bytes, hipMemcpyDeviceToHost));
+  return AFC_OK;
+}
+
+int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters, float *resid_linf) {
+  if (check_env(env)) return AFC_EINVAL;
+  if (!ux || !uy || !p) return fail(AFC_EINVAL, "afc_op_project: null argument");
+  if (env->P.impl == 0) return fail(AFC_EINVAL, "afc_op_project: impl 2 only (the fused projection of the optimised kernels)");
+  if (env->P.gs_mode != 0) return fail(AFC_EINVAL, "afc_op_project: not available in perf mode (gs_mode 1)");
+  HIP_TRY(hipSetDevice(env->cfg.device));
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  const StepParams &P = env->P;
+  const size_t bytes = (size_t)P.N * sizeof(float);
+  HIP_TRY(hipMemcpy(G(P.fx), ux, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.fy), uy, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.p), p, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(G(P.d), p, bytes, hipMemcpyHostToDevice));  // cells the solver never writes keep p's values
+  int *dit = reinterpret_cast<int *>(env->d_i32);
+  float *dl = env->d_f1, *dsh = env->d_f2;
+  StepParams Pq = P;
+  Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
+  Pq.stamps = nullptr;
+  if (need_diag(env))
+    afc::launch_op_project_diag(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
+  else
+    afc::launch_op_project_prod(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
+  int rc = launch_check("k_op_project");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(env->stream));
+  std::vector<float> ph((size_t)P.N);
+  HIP_TRY(hipMemcpy(ux, G(P.fx), bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(uy, G(P.fy), bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ph.data(), G(P.d), bytes, hipMemcpyDeviceToHost));
+  int it = 0;
+  float l = 0, sh = 0;
+  HIP_TRY(hipMemcpy(&it, dit, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&l, dl, sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&sh, dsh, sizeof(float), hipMemcpyDeviceToHost));
+  // the kernels keep the mean shift pending (project_tail_v2); p.plusEq(s) is this float addition (VectorField.pde:136)
+  for (int k = 0; k < P.N; ++k) p[k] = ph[(size_t)k] + sh;
+  if (iters) *iters = it;
+  if (resid_linf) *resid_linf = l;
   return AFC_OK;
 }
 
@@ -1101,6 +1157,44 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   HIP_TRY(hipMemcpy(&l, dl, sizeof(float), hipMemcpyDeviceToHost));
   if (iters) *iters = it;
   if (resid_linf) *resid_linf = l;
+  return AFC_OK;
+}
+
+int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s) {
+  if (!gb_per_s || bytes < (1u << 20) || reps < 1) return fail(AFC_EINVAL, "afc_measure_copy_rate: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(AFC_ENODEV, "afc_measure_copy_rate: no HIP device available");
+  if (device < 0 || device >= ndev) return fail(AFC_EINVAL, "afc_measure_copy_rate: device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  const size_t n4 = (size_t)(bytes / 16);
+  float4 *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc((void **)&a, n4 * 16));
+  if (hipMalloc((void **)&b, n4 * 16) != hipSuccess) {
+    (void)hipFree(a);
+    return fail(AFC_EHIP, "afc_measure_copy_rate: hipMalloc");
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipMemset(a, 0x3c, n4 * 16);
+  float best_ms = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {  // the first pass warms the TLB
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, nullptr, a, b, n4);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms < best_ms) best_ms = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  int rc = launch_check("k_copy_f4");
+  if (rc) return rc;
+  *gb_per_s = (float)(2.0 * 16.0 * (double)n4 / (best_ms * 1e-3) / 1e9);  // bytes read + bytes written
   return AFC_OK;
 }
 

@@ -221,7 +221,9 @@ __device__ __forceinline__ f2 quick_face2(f2 bLm, f2 bL, f2 bH, f2 bHp, f2 uf, l
 // consecutive rows of the block and carries the east-face flux down the rows; lane l owns C
 // adjacent columns and carries the north-face flux across them.  Non-interior cells of dst are
 // NOT written (setbc_vel defines them).
-template <int C>
+// (TAG: the unit-operator kernels instantiate their own copies -- a second call site of the same instance would make
+// the compiler outline it and change the step kernels' code)
+template <int C, int TAG = 0>
 __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
                                  float *__restrict__ dy, float *lds, const bool fold = false) {
@@ -440,8 +442,8 @@ __device__ __host__ __forceinline__ int adv3_lds_floats(int C) { return 4 * (2 *
 // in flight while the current row's faces are evaluated, and a wave only ever waits for its own counted vmcnt (all
 // vector-memory operations of a wave complete in order).  Issue order of row iteration i:
 //   copies of base row i+1 | copies of src row i+5 | wait: src row i+2 | faces | wait: base row i | last add | stores
-// For grids of exactly 64*C interior columns (m = 64*C + 2: every lane owns C cells; res = 8*C) and >= 8 rows per
-// wave; the caller uses advdif_v2 otherwise.
+// For grids of 64*C interior columns (one column tile) or of two column tiles of at most 64*C (see TILES below), >= 8
+// rows per wave; the caller uses advdif_v2 otherwise.
 // The lane index, recomputed where it is used (two VALU instructions): values derived from threadIdx.x that are live
 // across the whole kernel get spilled around the register-hungry loops and every reload inside such a loop is a
 // scratch load -- a vector-memory operation whose wait drains the staging copies in flight.
@@ -451,22 +453,35 @@ __device__ __forceinline__ unsigned lane_fresh() {
   return l;
 }
 
-template <int C>
+template <int C, int TAG = 0>
 __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
                                  float *__restrict__ dy, float *lds, const bool fold) {
   // fold: every row is stored WITH the wall columns setBC would give it (Field.pde:217-224: u.x mirrors the adjacent
-  // interior cell; u.y[.][0] = old u.y[.][1], then u.y[.][1] = u.y[.][m-1] = 0) by its first and last lane -- two
+  // interior cell; u.y[.][0] = old u.y[.][1], then u.y[.][1] = u.y[.][m-1] = 0) by the lane at the wall -- two
   // more store instructions per row -- so that what is left of setBC is whole-row work (setbc_rows)
-  constexpr int m = 64 * C + 2, LQ = (m + 3) >> 2, PR = 4 * LQ, NS = kAdvNS;
+  //
+  // TILES.  A wave's pipeline covers a contiguous run of rows of ONE column tile of W = lanes x C interior columns; its
+  // ring rows hold the W + 4 columns c0 .. c0 + W + 3 the tile's QUICK stencils reach (two columns either side).  Grids
+  // of 64*C interior columns are one tile wide and the four waves split the rows in quarters (256x128, 128x64).  Wider
+  // grids (384x192: W = 96, 48 lanes; 512x256: W = 128) are TWO tiles wide -- their rings would not fit the workgroup's
+  // 40 KB as whole rows -- and the waves are a 2 x 2 arrangement of row halves and column halves.  The only thing a
+  // right-hand tile cannot take from its neighbour is the south-face flux of its first column (lane 0 has no lane - 1):
+  // it evaluates that face itself, from the two halo columns, with the expression the left tile's last lane uses for
+  // its north face.
+  constexpr int PR = 64 * C + 4, NS = kAdvNS;    // floats per ring row (16-byte rows); ring rows per field
   const int ST = fold ? 4 : 2;  // store instructions per row iteration
   constexpr unsigned PRB = PR * 4u;              // bytes per ring row
   constexpr int YO = NS * PR;                    // floats from a row of the x ring to the same row of the y ring
-  constexpr int BO = 2 * NS * PR;                // floats from the x ring to the base rows: [buf][x|y]
-  const int n = uni(P.n), n_ = n - 2;
+  const int n = uni(P.n), n_ = n - 2, m = uni(P.m), m_ = m - 2;
   const int wave = uni((int)(threadIdx.x >> 6));
-  const int RPW = (n_ + 3) >> 2;
-  const int i_first = 1 + wave * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
+  const int ncol = (m_ > 64 * C) ? 2 : 1, nrow = 4 / ncol;
+  const int tcol = (ncol == 2) ? (wave & 1) : 0, trow = (ncol == 2) ? (wave >> 1) : wave;
+  const int W = m_ / ncol, lanes_on = W / C;
+  const int jlo = 1 + tcol * W, c0 = tcol ? jlo - 2 : 0;  // first interior column of the tile; column at ring index 0
+  const int LQ = (W + 7) >> 2;                            // 16-byte pieces of a staged row (W + 4 columns)
+  const int RPW = (n_ + nrow - 1) / nrow;
+  const int i_first = 1 + trow * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
   const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((2 * NS + 4) * PRB)));  // x ring
   const float nu = uni(P.nu), dt = uni(P.dt);
   const bool same = (bx == sx) && (by == sy);
@@ -477,8 +492,8 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
 #define ADV3_STAGE()                                                                   \
   {                                                                                    \
     const unsigned ln_ = lane_fresh();                                                 \
-    if (r_next >= 0 && r_next <= r_hi && ln_ < LQ) {                                   \
-      const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                    \
+    if (r_next >= 0 && r_next <= r_hi && ln_ < (unsigned)LQ) {                         \
+      const unsigned so_ = 4u * (unsigned)(r_next * m + c0) + 16u * ln_;               \
       lds_dma16(sx, so_, ring + (unsigned)s_next * PRB);                               \
       lds_dma16(sy, so_, ring + (unsigned)(s_next + NS) * PRB);                        \
     }                                                                                  \
@@ -488,8 +503,8 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
 #define ADV3_BASE(row)                                                                 \
   {                                                                                    \
     const unsigned ln_ = lane_fresh();                                                 \
-    if (ln_ < LQ) {                                                                    \
-      const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
+    if (ln_ < (unsigned)LQ) {                                                          \
+      const unsigned so_ = 4u * (unsigned)((row) * m + c0) + 16u * ln_;                \
       const unsigned lb_ = ring + (unsigned)(2 * NS + 2 * ((row) & 1)) * PRB;          \
       lds_dma16(bx, so_, lb_);                                                         \
       lds_dma16(by, so_, lb_ + PRB);                                                   \
@@ -502,9 +517,9 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
     for (int i = i_first; i <= i_last; ++i) {
       const int t = i - i_first;
       if (nb && i < i_last) ADV3_BASE(i + 1)
-      if (t > 0) ADV3_STAGE()  // row i+5 replaces row i-2 (dead: only the first row of the quarter reads its row i-2)
+      if (t > 0) ADV3_STAGE()  // row i+5 replaces row i-2 (dead: only the first row of the run reads its row i-2)
       {  // how many of the wave's youngest vector-memory operations may still be in flight once row i+2 has landed.
-        // Per iteration j, in order: nb base copies (row j+1, if j < i_last), 2 src copies (row j+5, if staged), 2
+        // Per iteration j, in order: nb base copies (row j+1, if j < i_last), 2 src copies (row j+5, if staged), ST
         // stores (row j); the first iteration issues its src copies last (row i-2 is still read by its west faces).
         int K;
         if (t >= 3) {  // the copies of row i+2 were issued in iteration i-3: followed by its stores unless that was the first
@@ -517,8 +532,8 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         }
         wait_vm_le(K);
       }
-      const int j0 = 1 + C * (int)lane_fresh();
-      const unsigned lo = ring + 4u * (unsigned)j0;
+      const int j0 = jlo + C * (int)lane_fresh();
+      const unsigned lo = ring + 4u * (unsigned)(j0 - c0);
       const int s1 = (s0 + 1 >= NS) ? s0 + 1 - NS : s0 + 1, s2 = (s0 + 2 >= NS) ? s0 + 2 - NS : s0 + 2,
                 s3 = (s0 + 3 >= NS) ? s0 + 3 - NS : s0 + 3, s4 = (s0 + 4 >= NS) ? s0 + 4 - NS : s0 + 4;
       const lds_f *r1 = (const lds_f *)(uintptr_t)(lo + (unsigned)s1 * PRB);
@@ -531,7 +546,7 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
       const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
       float oxv[C], oyv[C];
       f2 fEn[C], fNn[C], difv[C], ccv[C];
-      f2 fSw = {0.f, 0.f};  // lane 0: vs * 0.5*(cs + cc)
+      f2 fSw = {0.f, 0.f};  // lane 0 at the wall: vs * 0.5*(cs + cc)
 #pragma unroll
       for (int e = 0; e < C; ++e) {
         const int j = j0 + e;
@@ -539,7 +554,7 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
         const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
         ccv[e] = cc;
-        if (t == 0) {  // the quarter's first row: its west face (afterwards = the previous row's east face)
+        if (t == 0) {  // the run's first row: its west face (afterwards = the previous row's east face)
           const lds_f *r0 = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
           const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
           const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});
@@ -554,6 +569,13 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{r1[YO + e + 1], cn.y});
         fNn[e] = vn * quick_face2(cs, cc, cn, XY(r2, e + 2), vn, rok ? mC : 0, rok ? mCN : 0);
         difv[e] = ce + cn - 4.f * cc + cw + cs;  // VectorField.pde:198-200
+      }
+      if (tcol) {  // right-hand tile: lane 0's south face = the north face of column j0-1, evaluated here (e = -1 above)
+        const lmask mC = lanes_if((j0 - 1 >= 2) && (j0 - 1 <= m - 2));
+        const lmask mCN = lanes_if((j0 >= 2) && (j0 <= m - 2));
+        const f2 cc = XY(r2, -1), cn = XY(r2, 0), cs = XY(r2, -2);
+        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{r1[YO], cn.y});
+        fSw = vn * quick_face2(cs, cc, cn, XY(r2, 1), vn, rok ? mC : 0, rok ? mCN : 0);
       }
 #undef XY
       fSw.x = lane_prev_keep(fSw.x, fNn[C - 1].x);  // south face of the lane's first cell = north face of lane-1's last
@@ -580,18 +602,22 @@ __device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ 
         fE2[e] = fEn[e];
       }
       const unsigned ob = 4u * (unsigned)(i * m + j0);  // byte offset of the lane's cells of row i (32-bit: SGPR base + offset)
+      const unsigned ln_ = lane_fresh();
       if (fold) {
-        const unsigned ln_ = lane_fresh();
-        if (ln_ == 0u || ln_ == 63u) {  // both lanes exist in every wave: always two store instructions
-          const bool first = (ln_ == 0u);
+        // the lane at the lower wall (lane 0 of a left-hand tile) and the lane at the upper wall (the last lane of a
+        // right-hand tile): at least one of them exists in every wave, so these are always two store instructions
+        const bool first = (ln_ == 0u) && (tcol == 0), last = (ln_ == (unsigned)(lanes_on - 1)) && (tcol == ncol - 1);
+        if (first || last) {
           const unsigned gb = 4u * (unsigned)(i * m + (first ? 0 : m - 1));
           st1b(dx, gb, first ? oxv[0] : oxv[C - 1]);
           st1b(dy, gb, first ? oyv[0] : 0.f);
         }
-        if (ln_ == 0u) oyv[0] = 0.f;
+        if (first) oyv[0] = 0.f;
       }
-      __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
-      __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
+      if (ln_ < (unsigned)lanes_on) {  // (a tile of 96 columns leaves the upper 16 lanes idle)
+        __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
+        __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
+      }
       asm volatile("" ::: "memory");
       if (t == 0) ADV3_STAGE()  // row i+5 replaces row i-2, whose last reader was this row's west face
       s0 = s1;
@@ -2421,6 +2447,191 @@ __device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The descending leg of a COARSE level (mg_down_fused<false, true>: d = r*inv; d.setBC; x = 0 + d; r -= A d;
+// r_c = restrict(r), MG.pde:69-70 with MG.pde:56,80,90-97,124-137) as FOUR INDEPENDENT ROW PIPELINES without a workgroup
+// barrier -- head_v3's shape for any level whose rows are 6 .. 32 chunks of four columns.  As blocks of 14*k rows
+// (mg_down_fused) the leg is twenty barrier-separated segments with a global round trip each on level 1 of the
+// 256x128 grid: 24 us for one env alone, 119 us with 1024 resident (profiles/r3_level_profile_*.txt).
+// Lanes: h = lane / CPR rows of a block of RPI = (64 / CPR) & ~1 rows (restriction pairs stay inside a block), c4 = lane
+// % CPR the chunk.  Wave w owns a contiguous run of row pairs.  Per iteration a wave (0) fetches r of the block two
+// ahead, (1) forms d = r*inv of the block one ahead into its private LDS ring (with the setBC mirror in the ghost
+// columns and rows), r staying in registers for one iteration, (2) finishes its block: x, r - A d and the restricted
+// residual (the even row's four residuals reach the odd row's lanes through ds_bpermute).  The rows just outside a
+// wave's run (one above, one below) are evaluated by both neighbours, from the level's r array, which this leg does
+// not modify: the new residual goes to the level's `d` scratch array (the up-leg reads it from there).
+// Same expressions, same order, same bits as mg_down_fused<false, true>.
+// ---------------------------------------------------------------------------------------------
+__device__ __host__ __forceinline__ int down3_rpi(int m_) { return (64 / (m_ >> 2)) & ~1; }
+__device__ __host__ __forceinline__ int down3_ns(int m_) {
+  int ns = 8;
+  while (ns < 2 * down3_rpi(m_) + 2) ns <<= 1;
+  return ns;
+}
+__device__ __host__ __forceinline__ bool down3_shape_ok(int n, int m) {
+  const int n_ = n - 2, m_ = m - 2;
+  return (m_ & 3) == 0 && (n_ & 1) == 0 && (m_ >> 2) >= 6 && (m_ >> 2) <= 32 && n_ >= 8;
+}
+__device__ __host__ __forceinline__ int down3_lds_floats(int m) {
+  const int m_ = m - 2;
+  return 4 * (down3_ns(m_) * (m_ + 4) + 8) + 8;
+}
+__device__ inline void down_v3c(const StepParams &P, const Lv &L0, const Lv &L1, float *lds) {
+  const int n = uni(L0.n), m = uni(L0.m), n_ = n - 2, m_ = m - 2;
+  const int CPR = m_ >> 2, PT = m_ + 4, RPI = down3_rpi(m_), NS = down3_ns(m_);
+  const LevelDesc &D = *L0.desc;
+  const float *rin = L0.r;
+  float *xout = L0.x, *rout = L0.d, *r1 = L1.r;
+  const float *lxp = L0.lx, *lyp = L0.ly, *invp = L0.inv;
+  const int m1 = uni(L1.m);
+  const float cu = uni(D.cu);
+  float it[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) it[q] = uni(D.invtab[q]);
+  const int sp_i0 = uni(D.sp_i0), sp_i1 = uni(D.sp_i1);
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int ppw = ((n_ >> 1) + 3) >> 2;  // row pairs per wave
+  const int i_first = 1 + 2 * wave * ppw, i_last = (i_first + 2 * ppw - 1 < n_) ? i_first + 2 * ppw - 1 : n_;
+  const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((unsigned)(NS * PT + 8) * 4u)));
+  // ring element (row R, column jj) at float index (R & (NS-1))*PT + jj + 3: a lane's four columns are one aligned 16 bytes
+#define DN_D4(R, c) (*(lds_f4 *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + 4 * (c) + 4)))
+#define DN_D1(R, jj) (*(lds_f *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + (jj) + 3)))
+  if (i_first <= n_) {
+    const unsigned ln = lane_fresh();
+    const int h = (int)((ln * ((65536u + (unsigned)CPR - 1u) / (unsigned)CPR)) >> 16), c4 = (int)ln - h * CPR;
+    const bool lane_on = h < RPI;
+    const int d_hi = (i_last + 1 < n_) ? i_last + 1 : n_;  // last row whose d this wave forms itself
+    // r of the block starting at row R0 (rows outside [lo, hi] and idle lanes: zeros, never used)
+    auto fetch = [&](int R0, int lo, int hi) {
+      F4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v.v[e] = 0.f;
+      const int R_ = R0 + h;
+      if (lane_on && R_ >= lo && R_ <= hi) v = ld4b(rin, 4u * (unsigned)(R_ * m + 1 + 4 * c4));
+      return v;
+    };
+    // step 1 on the block starting at row R0: d = r*inv into the ring
+    auto step1 = [&](int R0, int lo, int hi, const F4 &rv) {
+      const int R_ = R0 + h;
+      if (lane_on && R_ >= lo && R_ <= hi) {
+        const bool sp_ = (R0 + RPI - 1 >= sp_i0) && (R0 <= sp_i1);
+        F4 iv;
+        if (sp_) {
+          iv = ld4b(invp, 4u * (unsigned)(R_ * m + 1 + 4 * c4));
+        } else {
+          const bool rf = (R_ == 1), rl = (R_ == n_);  // inv = invtab[3*rowclass + colclass] (LevelDesc), from scalar registers
+          const float i0 = rf ? it[3] : (rl ? it[6] : it[0]);
+          iv.v[0] = (c4 == 0) ? (rf ? it[4] : (rl ? it[7] : it[1])) : i0;
+          iv.v[1] = i0;
+          iv.v[2] = i0;
+          iv.v[3] = (c4 == CPR - 1) ? (rf ? it[5] : (rl ? it[8] : it[2])) : i0;
+        }
+        f4a d4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d4[e] = rv.v[e] * iv.v[e];  // MG.pde:80
+        DN_D4(R_, c4) = d4;
+        if (c4 == 0) DN_D1(R_, 0) = d4[0];  // d.setBC(): ghosts mirror the adjacent interior cell (Field.pde:211-224)
+        if (c4 == CPR - 1) DN_D1(R_, m_ + 1) = d4[3];
+        if (R_ == 1 || R_ == n_) {
+          const int Rg_ = (R_ == 1) ? 0 : n_ + 1;
+          DN_D4(Rg_, c4) = d4;
+          if (c4 == 0) DN_D1(Rg_, 0) = d4[0];
+          if (c4 == CPR - 1) DN_D1(Rg_, m_ + 1) = d4[3];
+        }
+      }
+    };
+    F4 c_r0, nx_r;
+    {
+      const int ra = i_first - RPI;  // the block whose last row is the row above the run
+      const F4 ta = fetch(ra, (i_first - 1 > 1 ? i_first - 1 : 1), i_first - 1);
+      c_r0 = fetch(i_first, i_first, d_hi);
+      nx_r = fetch(i_first + RPI, i_first + RPI, d_hi);
+      step1(ra, (i_first - 1 > 1 ? i_first - 1 : 1), i_first - 1, ta);
+      step1(i_first, i_first, d_hi, c_r0);
+    }
+    asm volatile("" ::: "memory");
+    for (int g = i_first; g <= i_last; g += RPI) {
+      const F4 pf_r = fetch(g + 2 * RPI, g + 2 * RPI, d_hi);
+      step1(g + RPI, g + RPI, d_hi, nx_r);
+      // lanes read below what OTHER lanes of the wave have just stored: program order must survive the optimiser; in
+      // hardware the LDS operations of a wave execute in order
+      asm volatile("" ::: "memory");
+      const int G_ = g + h, j = 1 + 4 * c4;
+      const bool on2 = lane_on && G_ <= i_last;
+      F4 ro;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ro.v[e] = 0.f;
+      if (on2) {  // ---- step 2: rows g .. g+RPI-1 ----
+        const unsigned kb = 4u * (unsigned)(G_ * m + j);
+        const bool sp = (g + RPI - 1 >= sp_i0) && (g <= sp_i1);
+        F4 lw, le, ls;
+        float ln4;
+        if (sp) {
+          lw = ld4b(lxp, kb);
+          le = ld4b(lxp, kb + 4u * (unsigned)m);
+          ls = ld4b(lyp, kb);
+          ln4 = ld1b(lyp, kb + 16u);
+        } else {  // coef_analytic on a level with zeroed boundary faces (MG.pde:120)
+          const float lwr = (G_ == 1) ? 0.f : cu, ler = (G_ == n_) ? 0.f : cu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lw.v[e] = lwr, le.v[e] = ler, ls.v[e] = cu;
+          if (c4 == 0) ls.v[0] = 0.f;
+          ln4 = (c4 == CPR - 1) ? 0.f : cu;
+        }
+        const f4a dc = DN_D4(G_, c4), dw = DN_D4(G_ - 1, c4), de = DN_D4(G_ + 1, c4);
+        const float dl = DN_D1(G_, j - 1), dr = DN_D1(G_, j + 4);
+        const float d6[6] = {dl, dc[0], dc[1], dc[2], dc[3], dr};
+        F4 xo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+          const float diag = -(lwv + lev + lsv + lnv);
+          const float d = d6[1 + e];
+          const float ad = d * diag + dw[e] * lwv + de[e] * lev + d6[e] * lsv + d6[2 + e] * lnv;  // PoissonMatrix.pde:57-61
+          ro.v[e] = c_r0.v[e] - ad;                                                              // MG.pde:96
+          xo.v[e] = (0.f + 0.f) + d;                                                             // MG.pde:56,95
+        }
+        st4b(xout, kb, xo);
+        st4b(rout, kb, ro);
+        // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+        if (c4 == 0) st1b(xout, kb - 4u, (0.f + 0.f) + d6[1]);
+        if (c4 == CPR - 1) st1b(xout, kb + 16u, (0.f + 0.f) + d6[4]);
+        if (G_ == 1 || G_ == n_) {
+          const unsigned kg = 4u * (unsigned)(((G_ == 1) ? 0 : (n - 1)) * m + j);
+          F4 xg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xg.v[e] = (0.f + 0.f) + d6[1 + e];
+          st4b(xout, kg, xg);
+          if (c4 == 0) st1b(xout, kg - 4u, (0.f + 0.f) + d6[1]);
+          if (c4 == CPR - 1) st1b(xout, kg + 16u, (0.f + 0.f) + d6[4]);
+        }
+      }
+      // restrict (MG.pde:124-137): sum of the 2x2 children in the reference order; the even row's residuals come from
+      // the lanes one row further down (all lanes take part in the exchange)
+      float up[4];
+      {
+        const int src = (int)(4u * (ln + (unsigned)CPR));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          up[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ro.v[e])));
+      }
+      if (on2 && !(h & 1)) {
+        const int ci = (G_ - 1) / 2 + 1, cj = 2 * c4 + 1;
+        float two[2];
+        two[0] = ro.v[0] + ro.v[1] + up[0] + up[1];
+        two[1] = ro.v[2] + ro.v[3] + up[2] + up[3];
+        __builtin_memcpy((char *)r1 + 4u * (unsigned)(ci * m1 + cj), two, 8);
+      }
+      asm volatile("" ::: "memory");
+      c_r0 = nx_r;
+      nx_r = pf_r;
+    }
+  }
+#undef DN_D4
+#undef DN_D1
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // The bottom of the V-cycle out of LDS.  Levels from LB on (the first level whose shorter side has at most 16 cells:
 // 32x16 and below on the 16:8 grids, ~700 cells in all) cost next to nothing in arithmetic but, done level by level through
 // global memory, a dozen barrier-separated passes with a round trip each per level -- 200 us of the 1 750 us sim-step
@@ -2692,6 +2903,9 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
   const int kc = P.nlev - 1;
   // levels LB .. kc run out of LDS (mg_bottom) where the host found room for them; LB > kc: level by level as before
   const int LB = (!AFC_RB && uni(P.bottom_lb) >= 2 && !(AFC_DBG_OF(P) & 128)) ? uni(P.bottom_lb) : kc + 1;
+  // coarse down-legs as per-wave row pipelines (down_v3c) where the host found room for their rings; the experiments
+  // that use a level's `d` scratch array themselves (dbg bits 2, 8) and dbg bit 4 keep the blocked form
+  const bool down3 = uni(P.down_v3) != 0 && !(AFC_DBG_OF(P) & (4 | 16 | 256));
   int iter = 0;
   float linf = 0.f, xsum = 0.f;
   while (iter < P.mg_max_iters) {
@@ -2706,6 +2920,8 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
         if (l == 0)
           mg_down_fused<false, false>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
+        else if (down3 && down3_shape_ok(F.n, F.m))  // barrier-free row pipelines; the new residual lands in F.d
+          down_v3c(P, F, Cc, lds);
         else  // coarse levels start from x = 0 (MG.pde:56): folded into the leg, never stored or re-read
           mg_down_fused<false, true>(P, F, Cc, nullptr, nullptr, nullptr, 0.f, lds);
       } else {
@@ -2736,7 +2952,9 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
     }
     for (int l = (LB <= kc ? LB - 1 : kc - 1); l >= 0; --l) {
       if (l == 0 && pf.stop == 4) return iter;
-      const Lv F = uni((l == 0) ? L0 : make_level(P, e, l)), Cc = uni(make_level(P, e, l + 1));
+      Lv F = uni((l == 0) ? L0 : make_level(P, e, l));
+      const Lv Cc = uni(make_level(P, e, l + 1));
+      if (l > 0 && down3 && down3_shape_ok(F.n, F.m) && ((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) F.r = F.d;  // where down_v3c left r
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2);
@@ -3000,7 +3218,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     float *pout = uni(half ? p0 : p1);
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (adv3_ok)
-      advdif_v3<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
+      advdif_v3<(C > 2 ? 2 : C)>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     else
       advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     pf.mark(PF_ADVDIF);

