@@ -396,7 +396,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * cells * sim_per_launch,
                          "copy_ceiling_measured_GBs": round(copy_bw / 1e9, 1) if copy_bw else None,
                          "frac_of_measured_copy_ceiling": round(achieved / copy_bw, 5) if copy_bw else None,
-                         "copy_ceiling_kernel": "afc_measure_copy_rate: float4 copy, 1 GiB, 2048 x 256 threads",
+                         "copy_ceiling_kernel": "afc_measure_copy_rate: hand-written float4 copy, 1 GiB, best of plain / non-temporal x 2048 / 8192 workgroups",
                          "torch_copy_GBs": round(torch_copy_bw / 1e9, 1) if torch_copy_bw else None},
         }
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be driven from inside

@@ -101,7 +101,9 @@ typedef struct afc_config {
                            iterate for iterate (every parity test runs in this mode; the headline benchmark too);
                            1 = PERF MODE: red-black Gauss-Seidel (4 sweeps = 8 half-sweeps per smooth), a different
                            but equally convergent smoother -- results agree with the reference to the tolerance stated
-                           in DESIGN.md and tests/test_gpu_perfmode.py, not bit for bit */
+                           in DESIGN.md and tests/test_gpu_perfmode.py, not bit for bit.  Perf mode carries no diagnostics:
+                           afc_create refuses it together with stagger_us != 0 or reserved[0] != 0, afc_profile_phases
+                           refuses to enable stamps; afc_op_mg_solve / afc_op_project run the red-black smoother too */
   int32_t reserved2[2];
 } afc_config;
 
@@ -206,8 +208,8 @@ int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters,
 int afc_op_setbc_u(afc_env *env, float *ux, float *uy);
 
 /* Measurement helper, no counterpart in the reference: the device-to-device copy rate of the box, bench.py's
- * "copy ceiling" -- a hand-written 16-byte-per-lane copy of `bytes` bytes (2048 workgroups x 256 threads, grid stride),
- * best of `reps` passes; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
+ * "copy ceiling" -- a hand-written 16-byte-per-lane copy of `bytes` bytes (256-thread workgroups, eight loads in flight
+ * per thread; default-policy and non-temporal accesses on 2048 and 8192 workgroups), best pass of `reps` per form; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
 int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s);
 
 #ifdef __cplusplus

@@ -29,11 +29,27 @@ FLAGS = (os.environ.get("AFC_EXTRA_FLAGS", "").split()) + ["-O3", "-std=c++17", 
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
+STAMP = os.path.join(HERE, "build", "flags.stamp")
+
+
+def _flag_string():
+    """the effective compile + link flags: a library built with other flags (AFC_EXTRA_FLAGS) is not reused silently"""
+    return " ".join(FLAGS) + " | HIPCC=" + os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    if any(os.path.getmtime(d) > t for d in _deps()):
+        return True
+    if os.environ.get("AFC_EXTRA_FLAGS") or os.path.exists(STAMP):
+        # a stamp exists only next to a library this module built: compare the flags it was built with
+        try:
+            return open(STAMP).read() != _flag_string()
+        except OSError:
+            return True
+    return False
 
 
 def build(force=False, verbose=False):
@@ -51,27 +67,39 @@ def build(force=False, verbose=False):
                 objdir = os.path.join(HERE, "build")
                 os.makedirs(objdir, exist_ok=True)
                 jobs = []
-                for src in SOURCES:
-                    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".%d.o" % os.getpid())
-                    cmd = [hipcc] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, src)]
-                    if verbose:
-                        print(" ".join(cmd))
-                    jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-                failed = []
-                for obj, cmd, pr in jobs:
-                    out = pr.communicate()[0].decode(errors="replace")
-                    if pr.returncode != 0:
-                        failed.append((cmd, out))
-                    elif verbose and out.strip():
-                        print(out)
-                if failed:
-                    for cmd, out in failed:
-                        sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
-                    raise subprocess.CalledProcessError(1, failed[0][0])
-                subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + [j[0] for j in jobs])
-                for obj, _, _ in jobs:
-                    os.remove(obj)
-                os.replace(tmp, LIB)
+                try:
+                    for src in SOURCES:
+                        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".%d.o" % os.getpid())
+                        cmd = [hipcc] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, src)]
+                        if verbose:
+                            print(" ".join(cmd))
+                        jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                    failed = []
+                    for obj, cmd, pr in jobs:
+                        out = pr.communicate()[0].decode(errors="replace")
+                        if pr.returncode != 0:
+                            failed.append((cmd, out))
+                        elif verbose and out.strip():
+                            print(out)
+                    if failed:
+                        for cmd, out in failed:
+                            sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
+                        raise subprocess.CalledProcessError(1, failed[0][0])
+                    # the extra flags reach the link step too (a CPU-side -fsanitize needs its runtime there)
+                    extra = os.environ.get("AFC_EXTRA_FLAGS", "").split()
+                    subprocess.check_call([hipcc] + extra + ["-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] +
+                                          [j[0] for j in jobs])
+                    os.replace(tmp, LIB)
+                    with open(STAMP, "w") as f:
+                        f.write(_flag_string())
+                finally:  # object files never outlive the call, whether a translation unit failed or not
+                    for obj, _, pr in jobs:
+                        if pr.poll() is None:
+                            pr.wait()
+                        if os.path.exists(obj):
+                            os.remove(obj)
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB

@@ -130,11 +130,32 @@ __global__ __launch_bounds__(afc::kThreads) void k_op_setbc(StepParams P) {
   afc::phase_setbc_u(P, 0, sm);
 }
 
-// Measurement helper (bench.py's copy ceiling): a plain 16-byte-per-lane device-to-device copy, 2048 workgroups of 256
-// threads walking the buffer with a grid stride -- the hard ceiling a streaming pass of this shape can reach on the box.
-__global__ __launch_bounds__(256) void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+// Measurement helper (bench.py's copy ceiling): a plain 16-byte-per-lane device-to-device copy -- 2048 workgroups of 256
+// threads, every thread with eight independent 16-byte loads in flight before its first store, tiles of 32 KB dealt
+// to the workgroups with a grid stride -- the hard ceiling a streaming pass can reach on the box.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy_f4(const f4v *__restrict__ src, f4v *__restrict__ dst, size_t n4) {
+  constexpr int U = 8;
+  const size_t tile = (size_t)256 * U;
+  for (size_t base = (size_t)blockIdx.x * tile; base < n4; base += (size_t)gridDim.x * tile) {
+    f4v v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = base + (size_t)u * 256 + threadIdx.x;
+      if (k < n4) v[u] = NT ? __builtin_nontemporal_load(src + k) : src[k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = base + (size_t)u * 256 + threadIdx.x;
+      if (k < n4) {
+        if (NT)
+          __builtin_nontemporal_store(v[u], dst + k);
+        else
+          dst[k] = v[u];
+      }
+    }
+  }
 }
 }  // namespace
 
@@ -284,6 +305,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (cfg->gs_mode != 0 && cfg->gs_mode != 1) return fail(AFC_EINVAL, "afc_create: gs_mode must be 0 (lexicographic) or 1 (red-black)");
   if (cfg->gs_mode == 1 && cfg->impl != 2) return fail(AFC_EINVAL, "afc_create: gs_mode 1 needs impl 2");
   if (cfg->gs_mode == 1 && cfg->exact_sums) return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) and exact_sums (parity mode) exclude each other");
+  // the perf-mode instantiation of the kernels carries none of the diagnostics: refuse what it would silently ignore
+  if (cfg->gs_mode == 1 && (cfg->stagger_us != 0 || cfg->reserved[0] != 0))
+    return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) has no diagnostics: stagger_us and reserved[0] (dbg) must be 0");
   if (cfg->y_lengths * cfg->resolution > 256 && cfg->impl != 0) return fail(AFC_EINVAL, "afc_create: impl 2 supports up to 256 cells in y");
   int ndev = 0;
   hipError_t he = hipGetDeviceCount(&ndev);
@@ -345,7 +369,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   env->cpl = (P.impl == 0) ? 0 : ((sf.m - 2) + 63) / 64;
   {
     const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 8;  // advdif_v2 (16-byte aligned tiles)
-    const size_t rings = (size_t)afc::prod::gs_lds_floats(sf.m) + 64;  // mg_up_smooth (single-wave march, kept for A/B)
+    // mg_up_smooth's rings on the finest level, with the strip height of this grid's kernel instantiation (coarser
+    // levels have at most half the columns and always fit 16-row strips)
+    const size_t rings = (size_t)afc::prod::gs_lds_floats(sf.m, afc::prod::up_strip_h(((sf.m - 2) + 63) / 64)) + 64;
     size_t fl = tile > rings ? tile : rings;
     // multi-wave smoother: both rings of every level live in the same region; with four workgroups per CU a
     // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)
@@ -1033,6 +1059,7 @@ int afc_get_static(afc_env *env, int which, int level, float *out) {
 
 int afc_profile_phases(afc_env *env, int enable, int64_t *ticks_out, int count) {
   if (check_env(env)) return AFC_EINVAL;
+  if (env->P.gs_mode == 1 && enable) return fail(AFC_EINVAL, "afc_profile_phases: not available in perf mode (gs_mode 1): its kernels carry no phase stamps");
   HIP_TRY(hipSetDevice(env->cfg.device));
   HIP_TRY(hipStreamSynchronize(env->stream));
   if (ticks_out && count > 0) {
@@ -1093,7 +1120,6 @@ int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters,
   if (check_env(env)) return AFC_EINVAL;
   if (!ux || !uy || !p) return fail(AFC_EINVAL, "afc_op_project: null argument");
   if (env->P.impl == 0) return fail(AFC_EINVAL, "afc_op_project: impl 2 only (the fused projection of the optimised kernels)");
-  if (env->P.gs_mode != 0) return fail(AFC_EINVAL, "afc_op_project: not available in perf mode (gs_mode 1)");
   HIP_TRY(hipSetDevice(env->cfg.device));
   HIP_TRY(hipStreamSynchronize(env->stream));
   const StepParams &P = env->P;
@@ -1107,7 +1133,9 @@ int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters,
   StepParams Pq = P;
   Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
   Pq.stamps = nullptr;
-  if (need_diag(env))
+  if (P.gs_mode == 1)  // perf mode: the red-black smoother the env's step kernels use
+    afc::launch_op_project_perf(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
+  else if (need_diag(env))
     afc::launch_op_project_diag(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
   else
     afc::launch_op_project_prod(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
@@ -1143,7 +1171,9 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   float *dl = env->d_f1;
   StepParams Pq = P;
   Pq.gate_limit = 0;  // a single workgroup: nobody to take turns with
-  if (need_diag(env) || P.impl == 0)
+  if (P.gs_mode == 1)  // perf mode: the red-black smoother the env's step kernels use
+    afc::launch_op_mg_perf(env->lds_bytes, env->stream, Pq, dit, dl);
+  else if (need_diag(env) || P.impl == 0)
     afc::launch_op_mg_diag(env->lds_bytes, env->stream, Pq, dit, dl);
   else
     afc::launch_op_mg_prod(env->lds_bytes, env->stream, Pq, dit, dl);
@@ -1168,7 +1198,7 @@ int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s)
   if (device < 0 || device >= ndev) return fail(AFC_EINVAL, "afc_measure_copy_rate: device ordinal out of range");
   HIP_TRY(hipSetDevice(device));
   const size_t n4 = (size_t)(bytes / 16);
-  float4 *a = nullptr, *b = nullptr;
+  f4v *a = nullptr, *b = nullptr;
   HIP_TRY(hipMalloc((void **)&a, n4 * 16));
   if (hipMalloc((void **)&b, n4 * 16) != hipSuccess) {
     (void)hipFree(a);
@@ -1179,15 +1209,21 @@ int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s)
   (void)hipEventCreate(&e1);
   (void)hipMemset(a, 0x3c, n4 * 16);
   float best_ms = 1e30f;
-  for (int r = 0; r < reps + 1; ++r) {  // the first pass warms the TLB
-    (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, nullptr, a, b, n4);
-    (void)hipEventRecord(e1, nullptr);
-    (void)hipEventSynchronize(e1);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (r > 0 && ms < best_ms) best_ms = ms;
-  }
+  // default-policy and non-temporal accesses, 2048 and 8192 workgroups: the best of the four forms is the ceiling
+  for (int form = 0; form < 4; ++form)
+    for (int r = 0; r < reps + 1; ++r) {  // the first pass of a form warms the TLB
+      const dim3 grid((form & 2) ? 8192 : 2048);
+      (void)hipEventRecord(e0, nullptr);
+      if (form & 1)
+        hipLaunchKernelGGL(k_copy_f4<true>, grid, dim3(256), 0, nullptr, a, b, n4);
+      else
+        hipLaunchKernelGGL(k_copy_f4<false>, grid, dim3(256), 0, nullptr, a, b, n4);
+      (void)hipEventRecord(e1, nullptr);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (r > 0 && ms < best_ms) best_ms = ms;
+    }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(a);

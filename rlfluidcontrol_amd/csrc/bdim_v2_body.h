@@ -726,8 +726,15 @@ __device__ __host__ __forceinline__ int ring_pitch(int m) {
   const int lo = m + 34;
   return lo + ((12 - lo) & 31);
 }
-__device__ __host__ __forceinline__ int gs_lds_floats(int m) {
-  return AFC_KPAD + (2 * 24 /*kRing*/ + 2) * ring_pitch(m) + 3 * AFC_KPAD;
+// Strip height of the FINEST level's up-leg by kernel instantiation (columns per lane): both rings of a 16-row strip
+// (24 ring rows of ring_pitch(m) floats each) fit a workgroup's 40 KB share of the LDS up to 128 interior columns; wider
+// grids take shorter strips -- 12 rows at 192 columns, 8 at 256, lanes c >= H of every sweep idle -- so that four
+// workgroups per CU stay resident (as 16-row strips the 512x256 grid ran two workgroups per CU, 384x192 three).
+__device__ __host__ constexpr int up_strip_h(int cpl) { return cpl <= 2 ? 16 : (cpl == 3 ? 12 : 8); }
+// ring rows for strips of H rows: the march has rows I0-4 .. I0+H in flight and the exit reads one row further up
+__device__ __host__ constexpr int up_ring_rows(int H) { return H == 16 ? 24 : H + 6; }
+__device__ __host__ __forceinline__ int gs_lds_floats(int m, int H = 16) {
+  return AFC_KPAD + (2 * up_ring_rows(H) + 2) * ring_pitch(m) + 3 * AFC_KPAD;
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
@@ -760,14 +767,15 @@ constexpr int kPad = AFC_KPAD;  // >= 34: the last lanes run (and write zeros) u
 // fetched (ds_read2_b32): what they need was stored exactly kLag steps before their use, i.e. by the store just issued
 // (same wave: LDS operations execute in order), and the fetch has two to three steps to land.
 constexpr int kLag = 4;
-template <bool FAST, bool ZB = true>
+template <bool FAST, bool ZB = true, int H = 16>
 __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0) {
+  constexpr int NR = up_ring_rows(H);  // (= kRing for H = 16)
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = ring_pitch(m);
   const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
   const int i = I0 - k + c;
-  const bool row_ok = (i >= 1) && (i <= n_);
+  const bool row_ok = (i >= 1) && (i <= n_) && (H == 16 || c < H);  // strips of H < 16 rows: lanes c >= H have no row
   const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);  // clamped for addressing only
-  const int slot = (ic % kRing) * PW, slotE = ((ic + 1) % kRing) * PW;
+  const int slot = (ic % NR) * PW, slotE = ((ic + 1) % NR) * PW;
   const LevelDesc &D = *L.desc;
   float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
   if (FAST) {  // row-dependent part of the analytic inverse diagonal
@@ -780,7 +788,7 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
   // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
   // iteration and possibly one more at the end
-  const int steps = (m_ + 15 + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
+  const int steps = (m_ + (H - 1) + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
   const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
   // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
   // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
@@ -788,7 +796,7 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   const int jo = 1 - c - kLag * k;
   const float *p_rv = (row_ok ? rr + slot : zrow) + jo;
   const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
-  const float *p_cW = (rowW_ok ? dr + ((i - 1) % kRing) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
+  const float *p_cW = (rowW_ok ? dr + ((i - 1) % NR) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
   const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
   const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
   float *w_d = (row_ok ? dr + slot : dummy) + jo;
@@ -875,7 +883,8 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   }
   // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
   // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
-  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
+  // (lanes without a row -- H < 16 -- run the steady stretch on the zero row: they stay at zero, their stores go to the dummy row)
+  const bool all_rows = (I0 - 3 >= 1) && (I0 + H - 1 <= n_);
   const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
   int tau0 = 0;
   for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
@@ -1339,10 +1348,12 @@ constexpr int kStripH = 16, kStageShift = 3;
 __device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int PW, int I0, int h, bool special,
                                    const DescU &du) {
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
-  const int half = m_ >> 1;  // cells of one colour per row (a power of two on every level of the 16:8 grids)
+  // slots of one colour per row: ceil(m_ / 2) -- on a level of ODD width (the coarsest levels of the 384x192 grid:
+  // 3 and 1 columns) one colour has a cell more than the other; the slot past the last column is skipped below
+  const int half = (m_ + 1) >> 1;
   const int c = h & 1;
   const LevelDesc &D = *L.desc;
-  const bool pow2 = (half & (half - 1)) == 0;
+  const bool pow2 = (half & (half - 1)) == 0;  // half >= 1: m_ >= 1 on every level
   const int sh = 31 - __builtin_clz(half);
   const float cu = du.cu;
   for (int q = threadIdx.x; q < kStripH * half; q += kThreads) {
@@ -1350,6 +1361,7 @@ __device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int 
     const int i = I0 - h + rw;
     if (i < 1 || i > n_) continue;
     const int j = 1 + 2 * qq + ((c + i + 1) & 1);
+    if (j > m_) continue;
     const int so = (i % kRing) * PW + j;
     const float dW = (i > 1) ? dr[((i - 1) % kRing) * PW + j] : 0.f;
     const float dE = (i < n_) ? dr[((i + 1) % kRing) * PW + j] : 0.f;
@@ -1375,6 +1387,8 @@ __device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int 
 //   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
 // streamed strip by strip: r (and p on the finest level) cross HBM once, d never leaves LDS.
 // need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
+// HS: rows per strip (16; 12 / 8 on the finest level of the grids wider than 128 columns: up_strip_h)
+template <int HS = 16>
 __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
                                     float *rr_out,
                                     float *linf_out, ProfT &pf, float *xsum_out = nullptr, const int rmode = 0) {
@@ -1382,8 +1396,13 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   // with rmode 2 in the rare case a second V-cycle needs it); 2 = replay: same d, only r is stored
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   const int PW = ring_pitch(m);
+#if AFC_RB
+  constexpr int H = kStripH, NR = kRing;
+#else
+  constexpr int H = HS, NR = up_ring_rows(HS);
+#endif
   const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));  // diagnostics: phase marks for the level with n rows
-  float *rr = lds + kPad, *dr = rr + kRing * PW + kPad, *zrow = dr + kRing * PW + kPad, *dummy = zrow + PW + kPad;
+  float *rr = lds + kPad, *dr = rr + NR * PW + kPad, *zrow = dr + NR * PW + kPad, *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
@@ -1395,6 +1414,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   const bool chunked = ((m_ & 3) == 0);
   const DescU du = desc_u(D);
   UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
+  U.NR = NR;
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
   // a thread keeps its 4-column chunk and walks down the rows of its group: no integer division in the strip loops
@@ -1408,9 +1428,9 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
   for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;
   lds_barrier();
   int loaded = 0;  // rows 1..loaded are (or were) in the rings
-  for (int I0 = 1; I0 - kStageShift <= n_; I0 += kStripH) {
-    // ---- fill rows loaded+1 .. I0+kStripH: r (after the prolongation increment) and d0 = r*inv ----
-    const int hi = I0 + kStripH;
+  for (int I0 = 1; I0 - kStageShift <= n_; I0 += H) {
+    // ---- fill rows loaded+1 .. I0+H: r (after the prolongation increment) and d0 = r*inv ----
+    const int hi = I0 + H;
     const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
     if (chunked) {
       // four columns per thread: one 16-byte load of r (+ the coarse x it needs), four LDS stores
@@ -1446,7 +1466,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
           }
           dv = rv * iv;  // MG.pde:80
         }
-        const int sl = (g % kRing) * PW + j;
+        const int sl = (g % NR) * PW + j;
         rr[sl] = rv;
         dr[sl] = dv;
         g += rstep;
@@ -1462,7 +1482,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (mk) pf.mark(PF_UP0);
 #if AFC_RB
     {
-      const bool special = (I0 + kStripH >= du.sp_i0) && (I0 - kStageShift - 1 <= du.sp_i1);
+      const bool special = (I0 + H >= du.sp_i0) && (I0 - kStageShift - 1 <= du.sp_i1);
       for (int h = 0; h <= kStageShift; ++h) {
         gs_rb_stage(F, rr, dr, PW, I0, h, special, du);
         lds_barrier();
@@ -1470,14 +1490,14 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     }
 #else
     if (tid < 64) {
-      const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
+      const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
-        gs_march3<false>(F, rr, dr, zrow, dummy, I0);
+        gs_march3<false, true, H>(F, rr, dr, zrow, dummy, I0);
       else if (du.zb)
-        gs_march3<true, true>(F, rr, dr, zrow, dummy, I0);
+        gs_march3<true, true, H>(F, rr, dr, zrow, dummy, I0);
       else
-        gs_march3<true, false>(F, rr, dr, zrow, dummy, I0);
+        gs_march3<true, false, H>(F, rr, dr, zrow, dummy, I0);
       __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();
@@ -1485,7 +1505,7 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
     if (mk) pf.mark(PF_GS0);
     // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
     const int e0 = (I0 - kStageShift - 1 < 1) ? 1 : I0 - kStageShift - 1,
-              e1 = (I0 + kStripH - kStageShift - 1 >= n_) ? n_ : I0 + kStripH - kStageShift - 2;
+              e1 = (I0 + H - kStageShift - 1 >= n_) ? n_ : I0 + H - kStageShift - 2;
     const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
     if (chunked) {
       if (grp_on)
@@ -1501,10 +1521,10 @@ __device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, 
           const int kk = g * m + j;
           const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
           const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
-          const int sl = (g % kRing) * PW;
+          const int sl = (g % NR) * PW;
           const float d = dr[sl + j];
           if (need_r) {
-            const float dW = dr[(gw % kRing) * PW + j], dE = dr[(ge % kRing) * PW + j];
+            const float dW = dr[(gw % NR) * PW + j], dE = dr[(ge % NR) * PW + j];
             const float dS = dr[sl + js], dN = dr[sl + jn];
             float lw, le, ls, ln, iv;
             if (sp_exit) {
@@ -2897,6 +2917,8 @@ __device__ inline void mg_bottom(const StepParams &P, size_t e, int LB, float *l
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
 // (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
 // kernels only -- and its 248 VGPRs would halve the occupancy of every kernel that calls it)
+// H0: strip height of the finest level's up-leg (up_strip_h of the kernel instantiation)
+template <int H0 = 16>
 __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
                                   const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
                                   ProfT &pf, float *lds, bool fused_head = true) {
@@ -2945,7 +2967,7 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
       if (!(AFC_DBG_OF(P) & 4))
-        mg_up_smooth(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+        mg_up_smooth<16>(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       else
         mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
@@ -2965,8 +2987,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
                               (AFC_DBG_OF(P) & 256);
       if (two_strips)
         mg_up_smooth2(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-      else if (!(AFC_DBG_OF(P) & 4))
-        mg_up_smooth(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else if (!(AFC_DBG_OF(P) & 4)) {
+        if (H0 != 16 && l == 0)
+          mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+        else
+          mg_up_smooth<16>(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      }
       else
         mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
@@ -2974,7 +3000,7 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
         if (two_strips)
           mg_up_smooth2(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else if (!(AFC_DBG_OF(P) & 4))
-          mg_up_smooth(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+          mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
       }
@@ -3130,7 +3156,7 @@ __device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, flo
 
 // u.project(c, p) (VectorField.pde:130-143).  pin holds the previous pressure (+ pending shift),
 // the result is left in pout (a different buffer) with a new pending shift *shift_io.
-template <int C>
+template <int C, int TAG = 0>
 __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e, float *vx, float *vy,
                                  const float *pin, float *pout,
                                  float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
@@ -3140,7 +3166,7 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   L0.x = pout;
   L0.d = G(P.u0y) + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
   float xsum = 0.f;
-  const int iters = mg_solve_v2(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
+  const int iters = mg_solve_v2<up_strip_h(C)>(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
   if (pf.stop >= 3 && pf.stop <= 5) return iters;
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
@@ -3187,8 +3213,10 @@ __device__ __forceinline__ void eval_force_wave(const StepParams &P, const float
   *fyo = py * -1.f;
 }
 
+// (forced inline, like mg_solve_v2: outlined, the diagnostic instantiation's copy would be shared by k_sim_step and
+// k_agent_step and allocated without their register cap)
 template <int C>
-__device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
+__device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
                                    ShBcast *sh, float *lds) {
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
@@ -3218,7 +3246,7 @@ __device__ inline void sim_step_v2(const StepParams &P, size_t e, float xi1_m, f
     float *pout = uni(half ? p0 : p1);
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (adv3_ok)
-      advdif_v3<(C > 2 ? 2 : C)>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
+      advdif_v3<(C > 2 ? 2 : C), C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);  // TAG = C: one instance per kernel instantiation
     else
       advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
     pf.mark(PF_ADVDIF);

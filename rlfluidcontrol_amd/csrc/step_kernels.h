@@ -172,6 +172,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
 }
 
 // unit-level operators on env 0 (same device functions as the step, chosen the way sim_step_v2 chooses them)
+#if AFC_MODE != 2
 template <int MODE>
 __global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, int same) {
   extern __shared__ float lds_dyn[];
@@ -192,9 +193,9 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, in
 #define ADV(c)                                                                                    \
   {                                                                                               \
     if (v3)                                                                                       \
-      afc::AFC_MODE_NS::advdif_v3<(c > 2 ? 2 : c), 1>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn, false); \
+      afc::AFC_MODE_NS::advdif_v3<(c > 2 ? 2 : c), 10 + c>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn, false); \
     else                                                                                          \
-      afc::AFC_MODE_NS::advdif_v2<c, 1>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn);    \
+      afc::AFC_MODE_NS::advdif_v2<c, 10 + c>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn);    \
   }
   if (m_ <= 64) ADV(1)
   else if (m_ <= 128) ADV(2)
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, in
   else ADV(4)
 #undef ADV
 }
+#endif
 // VectorField.project (VectorField.pde:130-143) on env 0: u in (fx, fy), p in P.p; the solution is left in P.d with its
 // pending mean shift in *shift_out (project_v2: fused head, coarse legs, up-legs, projection tail -- what a half-step runs)
 template <int MODE>
@@ -211,9 +213,16 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_project(StepParams P, i
   float shift = 0.f, l = 0.f;
   afc::AFC_MODE_NS::ProfT pf;
   pf.start(P);
-  const int it = afc::AFC_MODE_NS::project_v2<0>(false, P, 0,  // <0>: an instance of its own (see advdif_v2's TAG)
-                                                 G(P.fx), G(P.fy), G(P.p), G(P.d), &shift, nullptr, nullptr,
-                                                 nullptr, nullptr, sm, &l, pf, lds_dyn);
+  const int m_ = P.m - 2;
+  int it;
+  // TAG 1: instances of their own (see advdif_v2's TAG); the column count selects what the step kernel of this grid runs
+#define PROJ(c)                                                                                                       \
+  it = afc::AFC_MODE_NS::project_v2<c, 1>(false, P, 0, G(P.fx), G(P.fy), G(P.p), G(P.d), &shift, nullptr, nullptr, \
+                                           nullptr, nullptr, sm, &l, pf, lds_dyn)
+  if (m_ <= 128) PROJ(2);
+  else if (m_ <= 192) PROJ(3);
+  else PROJ(4);
+#undef PROJ
   if (threadIdx.x == 0) {
     *iters = it;
     *linf = l;
@@ -251,7 +260,13 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_mg(StepParams P, int *i
     float xs;
     afc::AFC_MODE_NS::ProfT pf;
     pf.start(P);
-    it = afc::AFC_MODE_NS::mg_solve_v2(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    const int m_ = P.m - 2;
+    if (m_ <= 128)
+      it = afc::AFC_MODE_NS::mg_solve_v2<16>(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    else if (m_ <= 192)
+      it = afc::AFC_MODE_NS::mg_solve_v2<afc::AFC_MODE_NS::up_strip_h(3)>(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
+    else
+      it = afc::AFC_MODE_NS::mg_solve_v2<afc::AFC_MODE_NS::up_strip_h(4)>(P, 0, L0v, nullptr, nullptr, nullptr, 0.f, sm, &l, &xs, pf, lds_dyn, false);
   }
   if (threadIdx.x == 0) {
     *iters = it;
@@ -291,17 +306,17 @@ void AFC_FN(launch_agent_step_)(int cpl, int E, size_t lds, hipStream_t st, cons
 #undef LAUNCH
   }
 }
-#if AFC_MODE != 2
+#if AFC_MODE != 2  // (the advection pass has no smoother in it: a perf-mode env runs the shipped operator kernel)
 void AFC_FN(launch_op_advdif_)(size_t lds, hipStream_t st, const StepParams &P, int same) {
   hipLaunchKernelGGL(k_op_advdif<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, same);
 }
+#endif
 void AFC_FN(launch_op_project_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl, float *dshift) {
   hipLaunchKernelGGL(k_op_project<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl, dshift);
 }
 void AFC_FN(launch_op_mg_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl) {
   hipLaunchKernelGGL(k_op_mg<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl);
 }
-#endif
 #if AFC_MODE == 1
 int occupancy_agent_step_diag(int cpl, size_t lds, int *per_cu) {
   switch (cpl) {

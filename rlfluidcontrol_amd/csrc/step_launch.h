@@ -21,6 +21,8 @@ void launch_op_advdif_prod(size_t lds, hipStream_t st, const StepParams &P, int 
 void launch_op_advdif_diag(size_t lds, hipStream_t st, const StepParams &P, int same);
 void launch_op_project_prod(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl, float *dshift);
 void launch_op_project_diag(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl, float *dshift);
+void launch_op_project_perf(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl, float *dshift);
+void launch_op_mg_perf(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl);
 void launch_op_mg_prod(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl);
 void launch_op_mg_diag(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl);
 int occupancy_agent_step_diag(int cpl, size_t lds, int *per_cu);

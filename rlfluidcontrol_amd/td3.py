@@ -201,9 +201,36 @@ class Agent:
             torch.manual_seed(seed)
         self.process_noise_generator = ProcessNoise(action_dim, batch=num_envs, device=self.device, dtype=torch.float32,
                                                     generator=self.gen)
+        if world > 1 and self.bs % world:
+            raise ValueError("sharded learner: the batch size %d must be a multiple of the world size %d" % (self.bs, world))
         self._build()
-        self.replay_buffer = ReplayBuffer(state_dim, action_dim, self.bfs, device=self.device)
+        if world > 1:
+            self._sync_from_rank0(seed)
+        # sharded learner: the job's replay capacity stays the reference's 1 M transitions (agent_TD3.py:27), a 1/world
+        # share per rank -- every rank stores the transitions of its own envs only
+        self.replay_buffer = ReplayBuffer(state_dim, action_dim, self.bfs // max(world, 1), device=self.device)
         self.step_count = self.total_step_count = self.episode_count = self.train_count = 0
+
+    def _nets(self):
+        return (self.main_actor, self.target_actor, self.main_critic_1, self.main_critic_2, self.target_critic_1,
+                self.target_critic_2)
+
+    def _sync_from_rank0(self, seed):
+        """sharded learner: every rank must start from the same weights and the same generator state (the ranks average
+        gradients onto THEIR weights and draw the same exploration / target noise).  With a process group up, rank 0's
+        are broadcast -- seeded or not; without one, only an explicit seed can guarantee it."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            if seed is None:
+                raise ValueError("Agent(world > 1) needs a seed or an initialised torch.distributed process group: "
+                                 "ranks that start from different weights never converge to one model")
+            return
+        for net in self._nets():
+            for p in net.parameters():
+                dist.broadcast(p.data, 0)
+        st = self.gen.get_state().to(self.device)
+        dist.broadcast(st, 0)
+        self.gen.set_state(st.cpu())
 
     def _build(self):
         s, a, dev = self.state_dim, self.action_dim, self.device
@@ -276,7 +303,7 @@ class Agent:
         self.n_grad_allreduce += 1
 
     def train_iter(self):
-        bs = self.bs if self.world <= 1 else -(-self.bs // self.world)  # this rank's share of the batch
+        bs = self.bs // max(self.world, 1)  # this rank's share of the batch (bs is a multiple of world: __init__)
         if bs > self.replay_buffer.size:
             return
         batch = self.replay_buffer.sample_batch(bs, generator=self.gen)
@@ -303,9 +330,11 @@ class Agent:
         self.step_count += 1
 
     def reset_agent(self):
-        self.replay_buffer = ReplayBuffer(self.state_dim, self.action_dim, self.bfs, device=self.device)
+        self.replay_buffer = ReplayBuffer(self.state_dim, self.action_dim, self.bfs // max(self.world, 1), device=self.device)
         self.step_count = self.total_step_count = self.train_count = self.episode_count = 0
         self._build()
+        if self.world > 1:
+            self._sync_from_rank0(0)  # a fresh model on every rank: rank 0's where a process group is up
 
     def reset_episode(self):
         self.step_count = 0

@@ -15,9 +15,12 @@ Every rank steps its shard and the one all-gather per agent step of `ShardedVecE
 observation; every rank evaluates the same actor on it (identical weights, identical generator state), the reference's
 only RL collective has the same shape (rank 0 asks the agent and `MPI_Bcast`s the two action values,
 clientNektar/Fourier/src/drive.C:1561).  The LEARNER IS SHARDED: a rank stores the transitions of its own envs only
-(E x 407 per episode -- the whole job's 8 x that would overflow the reference's 1 M-transition FIFO three times over at
-cfg5 scale) and trains on a 1/world share of every batch; the gradients are averaged with one all-reduce per optimiser
-step (~0.8 MB), so the weights stay bit-identical across ranks (tests/test_train_sharded_gloo.py).
+(E x 407 per episode) in a FIFO of 1/world of the reference's 1 M transitions -- the job keeps the reference's total
+replay capacity, but a batch is world equal shares drawn from the ranks' own FIFOs instead of one uniform draw over
+one FIFO (a deliberate deviation in sampling, not in capacity) -- and trains on a 1/world share of every batch (the
+batch size must be a multiple of the world size); the gradients are averaged with one all-reduce per optimiser step
+(~0.8 MB), so the weights stay bit-identical across ranks (tests/test_train_sharded_gloo.py): the ranks start from
+rank 0's weights and generator state (broadcast at construction, seeded or not).
 The rollout loop does not synchronise with the host per agent step: the number of agent steps of an episode is a
 function of the config alone (float32 time stepping, `episode_plan`), rewards are accumulated on the device, and the
 plan is checked against the device's `done` flags once, at the end.
@@ -36,18 +39,23 @@ from .vec_env import HipBackend, ShardedVecEnv
 
 def episode_plan(resolution, t_step=0.0075, init_time=1.0, end_time=50.0, substeps=16):
     """(agent-step calls, requests) of one episode started from t = 0 with a fresh averaging window, by the float32
-    bookkeeping of k_agent_step / clientCFD.pde:35-56: a call runs sim-steps until a window completes or t reaches
-    Time; a request follows every call whose window completed (408 requests)."""
+    bookkeeping of k_agent_step / clientCFD.pde:35-56: a call runs sim-steps until a window completes, t reaches Time
+    or the launch's step cap (afc_agent_step: warm-up steps + 2 windows + 8) is hit; a request follows every call whose
+    window completed (408 requests)."""
     import numpy as np
     f = np.float32
     dt = f(f(t_step) * f(resolution))
     inc = f(dt / f(resolution))
+    warm = int(f(init_time) / inc)
+    cap = max(warm, 0) + 2 * substeps + 8  # afc_agent_step's max_steps
     t, cl, calls, requests = f(0), substeps, 0, 0
     while t < f(end_time):
         calls += 1
         done_window = False
-        while t < f(end_time):
+        steps = 0
+        while t < f(end_time) and steps < cap:
             t = f(t + inc)
+            steps += 1
             if t > f(init_time):
                 cl -= 1
                 if cl <= 0:
@@ -62,12 +70,15 @@ def episode_plan(resolution, t_step=0.0075, init_time=1.0, end_time=50.0, subste
 def run_episode(vec, learner, max_requests=None, stochastic=True, plan=None):
     """One pass of the reference's draw() loop for all envs: returns (requests, mean reward per request).
     plan = (calls, requests) from `episode_plan`: the loop then runs without a host synchronisation per agent step
-    (all envs run the same fixed-dt episode in lock-step); without it the device's `done` flags are polled."""
+    (all envs run the same fixed-dt episode in lock-step); without it the device's `done` flags are polled.  A plan the
+    device disagrees with (envs not done after its last call: non-default time stepping the plan does not model) is
+    not fatal: the episode is finished by polling and `run_episode.plan_failed` is set so the caller stops using it."""
     W, E = vec.world, vec.E
     action = torch.zeros(W * E, 2, device=vec.device)
     learner.start_episode()
     n = 0
     rew_sum = torch.zeros((), device=vec.device)
+    run_episode.plan_failed = False
     if plan is not None:
         calls, requests = plan
         if max_requests is not None:
@@ -85,9 +96,9 @@ def run_episode(vec, learner, max_requests=None, stochastic=True, plan=None):
             n += 1
             if max_requests is not None and n >= max_requests:
                 break
-        if max_requests is None and not bool(done.all()):  # the one host synchronisation of the rollout
-            raise RuntimeError("episode plan (%d calls) and the device disagree: envs are not done" % calls)
-        return n, float(rew_sum) / max(n - 1, 1)
+        if max_requests is not None or bool(done.all()):  # the one host synchronisation of the rollout
+            return n, float(rew_sum) / max(n - 1, 1)
+        run_episode.plan_failed = True  # finish the episode the slow way
     while True:
         obs, rew, done = vec.step(action)
         ended = bool(done.all())
@@ -118,6 +129,8 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
     if init is not None:
         g.set_reset_state(init["u"], init["v"], init["p"])
     vec = ShardedVecEnv(HipBackend(g, dev), num_envs, device=dev)
+    if batch_size and batch_size % vec.world:
+        raise ValueError("batch_size %d must be a multiple of the world size %d (sharded learner)" % (batch_size, vec.world))
     learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed,
                                  shard=(vec.rank, vec.world))
     if batch_size:
@@ -131,6 +144,9 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
         g.reset()
         t0 = time.time()
         n, mean_r = run_episode(vec, learner, max_requests=max_requests, plan=plan)
+        if plan is not None and run_episode.plan_failed:
+            log("episode plan %r does not match the device (non-default time stepping?): polling from now on" % (plan,))
+            plan = None
         torch.cuda.synchronize(dev)
         t1 = time.time()
         learner.train(train_steps)

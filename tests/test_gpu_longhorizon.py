@@ -16,7 +16,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-N_STEPS = 3600        # >= 4 shedding periods on both grids (a period is ~780 sim-steps at res 16, ~885 at res 8; Re 100)
+N_STEPS = 4500        # >= 4 shedding periods (a period is ~785-840 sim-steps at res 16, ~885-910 at res 8; Re 100)
 SPINUP_RES8 = 9000    # res 8 has no committed developed wake: spun up on the GPU inside the test
 TOL_CD, TOL_CL, TOL_ST = 5e-3, 2e-2, 1e-2
 
@@ -69,8 +69,12 @@ def _gpu_history(envmod, res, state, xi, gs_mode):
     return f
 
 
-@pytest.mark.parametrize("xi", [(0.0, 0.0), (3.0, -2.0)])
-@pytest.mark.parametrize("res", [8, 16])
+# fixed non-zero actions (xi_m = act_scale * a, AFCCylinder.pde:48-49): on the 128x64 grid the control cylinders are one
+# cell across and a strong rotation stretches the shedding period beyond the window, so that grid gets a milder one
+ACTIONS = {8: [(0.0, 0.0), (1.0, -0.5)], 16: [(0.0, 0.0), (3.0, -2.0)]}
+
+
+@pytest.mark.parametrize("res,xi", [(r, a) for r in (8, 16) for a in ACTIONS[r]])
 def test_shedding_statistics_match_the_oracle(envmod, oracle_mod, res, xi):
     state = _developed_wake(envmod, res)
     o = oracle_mod.Oracle(resolution=res, Re=100)
