@@ -209,7 +209,8 @@ int afc_op_setbc_u(afc_env *env, float *ux, float *uy);
 
 /* Measurement helper, no counterpart in the reference: the device-to-device copy rate of the box, bench.py's
  * "copy ceiling" -- a hand-written 16-byte-per-lane copy of `bytes` bytes (256-thread workgroups, eight loads in flight
- * per thread; default-policy and non-temporal accesses on 2048 and 8192 workgroups), best pass of `reps` per form; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
+ * per thread; default-policy and non-temporal accesses on 2048 and 8192 workgroups; four placements of the buffer pair,
+ * because the rate depends on where the driver puts them), best pass of `reps` per form and placement; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
 int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s);
 
 #ifdef __cplusplus

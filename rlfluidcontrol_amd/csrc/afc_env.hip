@@ -3,6 +3,7 @@
 // fails with AFC_ENODEV when no HIP device is usable.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -169,6 +170,8 @@ struct afc_env {
   int io_space = AFC_MEM_HOST;
   int E = 0;
   std::vector<void *> allocs;
+  char *arena = nullptr;  // one allocation for all the small device buffers (tables shared by the envs, scalars, staging)
+  size_t arena_size = 0, arena_off = 0;
   float *rs_u = nullptr, *rs_v = nullptr, *rs_p = nullptr;  // reset state (device)
   float reset_flow_t = 0, reset_flow_dt = 0;
   // device staging for host-space I/O
@@ -191,10 +194,33 @@ struct afc_env {
 
 namespace {
 
+// Buffers of up to 16 MB come out of ONE arena per env (created on first use): the coefficient tables, the multigrid
+// hierarchy and the record table of mg_bottom -- what every workgroup keeps re-reading out of L2 -- then sit in one
+// contiguous range instead of wherever a dozen separate hipMalloc calls put them.  AFC_ARENA=0: separate allocations.
+constexpr size_t kArenaBytes = (size_t)96 << 20, kArenaMaxItem = (size_t)16 << 20;
 template <typename T>
 int dev_alloc(afc_env *env, T **p, size_t count) {
+  const size_t bytes = count * sizeof(T);
+  const char *ev = getenv("AFC_ARENA");
+  const bool use_arena = !(ev && atoi(ev) == 0);
+  if (use_arena && bytes <= kArenaMaxItem) {
+    if (!env->arena) {
+      void *a = nullptr;
+      HIP_TRY(hipMalloc(&a, kArenaBytes));
+      env->allocs.push_back(a);
+      env->arena = static_cast<char *>(a);
+      env->arena_size = kArenaBytes;
+      env->arena_off = 0;
+    }
+    const size_t off = (env->arena_off + 255) & ~(size_t)255;
+    if (off + bytes <= env->arena_size) {
+      *p = reinterpret_cast<T *>(env->arena + off);
+      env->arena_off = off + bytes;
+      return AFC_OK;
+    }
+  }
   void *q = nullptr;
-  HIP_TRY(hipMalloc(&q, count * sizeof(T)));
+  HIP_TRY(hipMalloc(&q, bytes));
   env->allocs.push_back(q);
   *p = static_cast<T *>(q);
   return AFC_OK;
@@ -394,6 +420,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.up2 = (P.impl != 0 && (size_t)afc::prod::gs2_lds_floats(sf.m) * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   P.head_v3 = (P.impl != 0 && sf.m == 130 && ((sf.n - 2) & 7) == 0 &&
                (size_t)afc::prod::kHeadLdsFloats * sizeof(float) <= env->lds_bytes) ? 1 : 0;
+  P.head_v4 = (P.impl != 0 && afc::prod::head4_shape_ok(sf.n, sf.m) &&
+               (size_t)afc::prod::head4_lds_floats(sf.m) * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   P.down_v3 = 0;
   if (P.impl != 0) {  // down_v3c: the rings of every level it would serve must fit the region
     P.down_v3 = 1;
@@ -515,13 +543,139 @@ int afc_create(const afc_config *cfg, afc_env **out) {
 
   const size_t E = (size_t)env->E;
   AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
-  for (AFC_AS1 float **f : fields) {
-    // + 64 floats: the row staging copies of advdif_v3 read up to 3 floats past the end of a row
-    if (!rc) rc = dev_alloc(env, f, E * P.Ns + 64);
-    if (!rc && hipMemset(G(*f), 0, (E * P.Ns + 64) * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  {
+    // The per-env state lives in ONE allocation (the eleven fine fields back to back, then the coarse scratch): the
+    // same library ran 7 % apart between env instances whose arrays came from separate hipMalloc calls (same box, same
+    // process, launches interleaved: tools/ab_inproc.py) -- where the driver happens to place a dozen 140 MB buffers
+    // decides how the streams of a phase fall on the memory channels / translation fragments.
+    // + 64 floats per field: the row staging copies of advdif_v3 read up to 3 floats past the end of a row.
+    // Development: AFC_ALLOC_MODE=0 restores separate allocations, AFC_ALLOC_STAGGER=<floats> offsets consecutive fields.
+    const char *am = getenv("AFC_ALLOC_MODE"), *as = getenv("AFC_ALLOC_STAGGER");
+    const int mode = am ? atoi(am) : 1;
+    const size_t stag = as ? (size_t)atol(as) : 0;
+    const size_t fsz = ((E * P.Ns + 64 + 63) / 64) * 64 + stag, csz = E * (size_t)P.Cs;
+    if (mode == 2) {  // experiment: every field its own allocation, the best 11 of 3 x 11 candidates by the streaming probe
+      std::vector<std::pair<float, float *>> cand;
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      const size_t n4 = fsz / 8;
+      for (int t = 0; t < 33 && !rc; ++t) {
+        void *q = nullptr;
+        if (hipMalloc(&q, fsz * sizeof(float)) != hipSuccess) {
+          (void)hipGetLastError();
+          break;
+        }
+        (void)hipMemsetAsync(q, 0, fsz * sizeof(float), nullptr);
+        float best = 1e30f;
+        for (int r = 0; r < 4; ++r) {
+          (void)hipEventRecord(e0, nullptr);
+          hipLaunchKernelGGL(k_copy_f4<false>, dim3(2048), dim3(256), 0, nullptr, (const f4v *)q, (f4v *)q + n4, n4);
+          (void)hipEventRecord(e1, nullptr);
+          (void)hipEventSynchronize(e1);
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (r > 0 && ms < best) best = ms;
+        }
+        cand.push_back({(float)(2.0 * 16.0 * (double)n4 / (best * 1e-3) / 1e9), static_cast<float *>(q)});
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      std::sort(cand.begin(), cand.end(), [](const std::pair<float, float *> &x, const std::pair<float, float *> &y) { return x.first > y.first; });
+      if (cand.size() < 11) rc = fail(AFC_EHIP, "hipMalloc");
+      for (size_t t = 0; t < cand.size(); ++t) {
+        if (getenv("AFC_PRINT_ALLOC")) fprintf(stderr, "afc_create: field candidate %p %.0f GB/s\n", (void *)cand[t].second, cand[t].first);
+        if (t < 11 && !rc) {
+          env->allocs.push_back(cand[t].second);
+          (void)hipMemset(cand[t].second, 0, fsz * sizeof(float));
+          *fields[t] = (AFC_AS1 float *)cand[t].second;
+        } else {
+          (void)hipFree(cand[t].second);
+        }
+      }
+      if (!rc) rc = dev_alloc(env, &P.coarse, csz);
+      if (!rc && hipMemset(G(P.coarse), 0, csz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+    } else if (mode == 0) {
+      for (AFC_AS1 float **f : fields) {
+        if (!rc) rc = dev_alloc(env, f, fsz);
+        if (!rc && hipMemset(G(*f), 0, fsz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+      }
+      if (!rc) rc = dev_alloc(env, &P.coarse, csz);
+      if (!rc && hipMemset(G(P.coarse), 0, csz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+    } else {
+      float *slab = nullptr;
+      const size_t total = 11 * fsz + csz;
+      // PLACEMENT.  Where the driver puts a buffer of this size decides what it streams at: the same copy kernel runs
+      // 4-5 % apart between 1.7 GB allocations of one process, the step kernel 6-7 % (bimodal, stable to 0.1 % per
+      // allocation; translation misses are nil either way: tools/ab_inproc.py, tools/scratch/alloc_probe.py).  Large
+      // batches therefore take the best of a few candidate allocations by a streaming probe (a copy of one half of
+      // the buffer onto the other, ~0.5 ms each) and give the others back.  AFC_PLACEMENT_TRIALS=1 switches it off.
+      const char *pt = getenv("AFC_PLACEMENT_TRIALS");
+      int trials = pt ? atoi(pt) : 12;  // at most; the search stops early once a fast candidate stands out (below)
+      if (total * sizeof(float) < ((size_t)256 << 20) || trials < 1) trials = 1;
+      if (trials > 16) trials = 16;
+      if (!rc && trials > 1) {
+        std::vector<float *> cand;
+        std::vector<float> rate;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        const size_t n4 = total / 8;  // 16-byte pieces of one half
+        for (int t = 0; t < trials; ++t) {
+          void *q = nullptr;
+          if (hipMalloc(&q, total * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+          }
+          cand.push_back(static_cast<float *>(q));
+          (void)hipMemsetAsync(q, 0, total * sizeof(float), nullptr);
+          float best = 1e30f;
+          for (int r = 0; r < 3; ++r) {
+            (void)hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(k_copy_f4<false>, dim3(2048), dim3(256), 0, nullptr, (const f4v *)q, (f4v *)q + n4, n4);
+            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms < best) best = ms;
+          }
+          rate.push_back((float)(2.0 * 16.0 * (double)n4 / (best * 1e-3) / 1e9));
+          // enough: both kinds of placement have been seen and the best is of the fast kind (the two modes are 4-5 % apart
+          // in this probe), or the candidates held so far take more than a third of the device's free memory
+          float lo = rate[0], hi = rate[0];
+          for (float v : rate) lo = v < lo ? v : lo, hi = v > hi ? v : hi;
+          size_t fr = 0, tot = 0;
+          const bool tight = (hipMemGetInfo(&fr, &tot) == hipSuccess) && fr < 2 * cand.size() * total * sizeof(float);
+          if ((cand.size() >= 3 && hi >= 1.04f * lo) || tight) break;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        int pick = -1;
+        for (size_t t = 0; t < cand.size(); ++t)
+          if (pick < 0 || rate[t] > rate[pick]) pick = (int)t;
+        for (size_t t = 0; t < cand.size(); ++t) {
+          if (getenv("AFC_PRINT_ALLOC"))
+            fprintf(stderr, "afc_create: candidate %zu at %p streams at %.0f GB/s%s\n", t, (void *)cand[t], rate[t], (int)t == pick ? "  <- kept" : "");
+          if ((int)t != pick) (void)hipFree(cand[t]);
+        }
+        if (pick >= 0) {
+          slab = cand[pick];
+          env->allocs.push_back(slab);
+          if (hipMemset(slab, 0, total * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+        }
+      }
+      if (!rc && !slab) {
+        rc = dev_alloc(env, &slab, total);
+        if (!rc && hipMemset(slab, 0, total * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+      }
+      if (!rc) {
+        if (getenv("AFC_PRINT_ALLOC")) fprintf(stderr, "afc_create: state slab %p, %zu bytes\n", (void *)slab, total * sizeof(float));
+        size_t k = 0;
+        for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + (k++) * fsz);
+        P.coarse = (AFC_AS1 float *)(slab + 11 * fsz);
+      }
+    }
   }
-  if (!rc) rc = dev_alloc(env, &P.coarse, E * (size_t)P.Cs);
-  if (!rc && hipMemset(G(P.coarse), 0, E * (size_t)P.Cs * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (!rc) rc = dev_alloc(env, &P.sc, E);
   if (!rc && hipMemset(G(P.sc), 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
   if (!rc) rc = dev_alloc(env, &env->rs_u, (size_t)P.Ns);
@@ -1198,36 +1352,46 @@ int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s)
   if (device < 0 || device >= ndev) return fail(AFC_EINVAL, "afc_measure_copy_rate: device ordinal out of range");
   HIP_TRY(hipSetDevice(device));
   const size_t n4 = (size_t)(bytes / 16);
-  f4v *a = nullptr, *b = nullptr;
-  HIP_TRY(hipMalloc((void **)&a, n4 * 16));
-  if (hipMalloc((void **)&b, n4 * 16) != hipSuccess) {
-    (void)hipFree(a);
+  // the rate depends on where the driver places the buffers (4-5 % between allocations of one process, see afc_create):
+  // a ceiling is the best of several placements, all held at once so that each is a different piece of memory
+  constexpr int kPlacements = 4;
+  f4v *buf[2 * kPlacements];
+  int got = 0;
+  for (; got < 2 * kPlacements; ++got)
+    if (hipMalloc((void **)&buf[got], n4 * 16) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+  if (got < 2) {
+    for (int q = 0; q < got; ++q) (void)hipFree(buf[q]);
     return fail(AFC_EHIP, "afc_measure_copy_rate: hipMalloc");
   }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  (void)hipMemset(a, 0x3c, n4 * 16);
   float best_ms = 1e30f;
-  // default-policy and non-temporal accesses, 2048 and 8192 workgroups: the best of the four forms is the ceiling
-  for (int form = 0; form < 4; ++form)
-    for (int r = 0; r < reps + 1; ++r) {  // the first pass of a form warms the TLB
-      const dim3 grid((form & 2) ? 8192 : 2048);
-      (void)hipEventRecord(e0, nullptr);
-      if (form & 1)
-        hipLaunchKernelGGL(k_copy_f4<true>, grid, dim3(256), 0, nullptr, a, b, n4);
-      else
-        hipLaunchKernelGGL(k_copy_f4<false>, grid, dim3(256), 0, nullptr, a, b, n4);
-      (void)hipEventRecord(e1, nullptr);
-      (void)hipEventSynchronize(e1);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      if (r > 0 && ms < best_ms) best_ms = ms;
-    }
+  for (int pl = 0; pl + 1 < got; pl += 2) {
+    f4v *a = buf[pl], *b = buf[pl + 1];
+    (void)hipMemset(a, 0x3c, n4 * 16);
+    // default-policy and non-temporal accesses, 2048 and 8192 workgroups: the best of the four forms is the ceiling
+    for (int form = 0; form < 4; ++form)
+      for (int r = 0; r < reps + 1; ++r) {  // the first pass of a form warms the TLB
+        const dim3 grid((form & 2) ? 8192 : 2048);
+        (void)hipEventRecord(e0, nullptr);
+        if (form & 1)
+          hipLaunchKernelGGL(k_copy_f4<true>, grid, dim3(256), 0, nullptr, a, b, n4);
+        else
+          hipLaunchKernelGGL(k_copy_f4<false>, grid, dim3(256), 0, nullptr, a, b, n4);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms < best_ms) best_ms = ms;
+      }
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  (void)hipFree(a);
-  (void)hipFree(b);
+  for (int q = 0; q < got; ++q) (void)hipFree(buf[q]);
   int rc = launch_check("k_copy_f4");
   if (rc) return rc;
   *gb_per_s = (float)(2.0 * 16.0 * (double)n4 / (best_ms * 1e-3) / 1e9);  // bytes read + bytes written

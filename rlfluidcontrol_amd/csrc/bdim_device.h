@@ -109,6 +109,7 @@ struct StepParams {
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
   int up2;             // 1: up-legs with two strips per round and two marching waves (mg_up_smooth2)
   int bottom_lb;       // first multigrid level of the LDS-resident bottom of the V-cycle (mg_bottom); 0 = none
+  int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows
   int bc_fold;         // 1: the row-streaming passes store the wall columns of u themselves, setBC is row work only (setbc_rows)
   const AFC_AS1 float *bottom_rec;  // its cell records {lw, le, ls, ln, inv, 0, 0, 0}, levels bottom_lb .. nlev-1 back to back

@@ -7,6 +7,27 @@
 //   C = (fx,fy)   corrector result; Heun average (A = (C+B)/2) lands back in A.
 // (included twice by bdim_v2.h: AFC_NS = prod with AFC_DIAG 0, AFC_NS = diag with AFC_DIAG 1)
 
+// Inlining of the phases (experiment hooks, build with AFC_EXTRA_FLAGS=-DAFC_ADV_ATTR=__noinline__ ...): `inline` leaves
+// the decision to the compiler, which inlines every phase into the step kernels (one register allocation for all).
+#ifndef AFC_ADV_ATTR
+#define AFC_ADV_ATTR inline
+#endif
+#ifndef AFC_HEAD_ATTR
+#define AFC_HEAD_ATTR inline
+#endif
+#ifndef AFC_TAIL_ATTR
+#define AFC_TAIL_ATTR inline
+#endif
+#ifndef AFC_UP_ATTR
+#define AFC_UP_ATTR inline
+#endif
+#ifndef AFC_DOWN_ATTR
+#define AFC_DOWN_ATTR inline
+#endif
+#ifndef AFC_BOT_ATTR
+#define AFC_BOT_ATTR inline
+#endif
+
 namespace afc {
 namespace AFC_NS {
 
@@ -454,7 +475,7 @@ __device__ __forceinline__ unsigned lane_fresh() {
 }
 
 template <int C, int TAG = 0>
-__device__ inline void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
+__device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
                                  float *__restrict__ dy, float *lds, const bool fold) {
   // fold: every row is stored WITH the wall columns setBC would give it (Field.pde:217-224: u.x mirrors the adjacent
@@ -1389,7 +1410,7 @@ __device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int 
 // need_r: also form/store r -= A d of the last increment and return r.r / L_inf (finest level).
 // HS: rows per strip (16; 12 / 8 on the finest level of the grids wider than 128 columns: up_strip_h)
 template <int HS = 16>
-__device__ inline void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+__device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
                                     float *rr_out,
                                     float *linf_out, ProfT &pf, float *xsum_out = nullptr, const int rmode = 0) {
   // rmode (finest level, chunked path): 0 = r written back; 1 = r not written back (the caller replays
@@ -2294,7 +2315,7 @@ constexpr int kHeadLdsFloats = 4 * (kHeadNS * 132 + 8) + 8;      // head_v3: fou
 // restricted r1 (the even row's four residuals come down to the odd row's lanes with v_permlane32_swap).  The rows
 // just outside a quarter (one above, one below) are evaluated by both neighbours.  Same expressions, same order, same
 // bits as mg_down_fused.
-__device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+__device__ AFC_HEAD_ATTR void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
                                const float *__restrict__ uy, const float *__restrict__ pin, float shift, float *lds) {
   constexpr int m = 130, m_ = 128, CPR = 32, PT = 132, NS = kHeadNS;
   const int n = uni(L0.n), n_ = n - 2;
@@ -2466,6 +2487,173 @@ __device__ inline void head_v3(const StepParams &P, const Lv &L0, const Lv &L1, 
   __syncthreads();
 }
 
+// The fused head on grids of 132 .. 256 interior columns (33 .. 64 chunks of four columns per row: 384x192, 512x256) as
+// four barrier-free row pipelines: head_v3's scheme with ONE ROW PER PASS of the wave (lane = chunk) -- a row pair is two
+// passes, so both rows of a restriction pair end up in the same lane and the restricted residual needs no lane
+// exchange.  Per iteration a wave forms r0 and d of rows g+2, g+3 (d into its private 8-row ring, r0 and p carried in
+// registers) and finishes rows g, g+1.  Same expressions, same order, same bits as mg_down_fused<true, false>.
+constexpr int kHead4NS = 8;
+__device__ __host__ __forceinline__ bool head4_shape_ok(int n, int m) {
+  const int n_ = n - 2, m_ = m - 2;
+  return (m_ & 3) == 0 && (m_ >> 2) > 32 && (m_ >> 2) <= 64 && (n_ & 7) == 0;
+}
+__device__ __host__ __forceinline__ int head4_lds_floats(int m) { return 4 * (kHead4NS * (m + 2) + 8) + 8; }
+__device__ AFC_HEAD_ATTR void head_v4(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
+                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift, float *lds) {
+  constexpr int NS = kHead4NS;
+  const int n = uni(L0.n), m = uni(L0.m), n_ = n - 2, m_ = m - 2, CPR = m_ >> 2, PT = m_ + 4;
+  const unsigned mb = 4u * (unsigned)m;  // bytes per grid row
+  const LevelDesc &D = *L0.desc;
+  float *pout = L0.x, *r = L0.r, *r1 = L1.r;
+  const float *lxp = L0.lx, *lyp = L0.ly, *invp = L0.inv;
+  const int m1 = uni(L1.m);
+  shift = uni(shift);
+  const float cu = uni(D.cu), iv0 = uni(D.invtab[0]);
+  const int sp_i0 = uni(D.sp_i0), sp_i1 = uni(D.sp_i1);
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int RPW = n_ >> 2;
+  const int i_first = 1 + wave * RPW, i_last = i_first + RPW - 1;
+  const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((unsigned)(NS * PT + 8) * 4u)));
+#define H4_D4(R, c) (*(lds_f4 *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + 4 * (c) + 4)))
+#define H4_D1(R, jj) (*(lds_f *)(uintptr_t)(ring + 4u * (unsigned)(((R) & (NS - 1)) * PT + (jj) + 3)))
+  struct Row {  // carried from step 1 to the next iteration's step 2: r0 and p of the lane's chunk, p left / right of it
+    F4 r0, pc;
+    float psl, pnr;
+  };
+  const int c4 = (int)lane_fresh();
+  const bool on = c4 < CPR;
+  const int j = 1 + 4 * c4;
+  const int d_hi = (i_last + 1 < n_) ? i_last + 1 : n_;  // last row whose d this wave forms itself
+  // ---- step 1 on row R_ (rows outside [lo_ok, hi_ok]: nothing) ----
+  auto step1 = [&](int R_, int lo_ok, int hi_ok) {
+    Row o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.r0.v[e] = o.pc.v[e] = 0.f;
+    o.psl = o.pnr = 0.f;
+    if (on && R_ >= lo_ok && R_ <= hi_ok) {
+      const unsigned kb_ = 4u * (unsigned)(R_ * m + j);
+      const bool sp_ = (R_ >= sp_i0) && (R_ <= sp_i1);
+      const F4 uxc = ld4b(ux, kb_), uxe = ld4b(ux, kb_ + mb), uyc = ld4b(uy, kb_);
+      const float uyn = ld1b(uy, kb_ + 16u);
+      const F4 pc = ld4b(pin, kb_), pw = ld4b(pin, kb_ - mb), pe = ld4b(pin, kb_ + mb);
+      const float psl = ld1b(pin, kb_ - 4u), pnr = ld1b(pin, kb_ + 16u);
+      F4 lw, le, ls, iv;
+      float ln4;
+      if (sp_) {
+        lw = ld4b(lxp, kb_);
+        le = ld4b(lxp, kb_ + mb);
+        ls = ld4b(lyp, kb_);
+        ln4 = ld1b(lyp, kb_ + 16u);
+        iv = ld4b(invp, kb_);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = cu, iv.v[e] = iv0;
+        ln4 = cu;
+      }
+      f4a d4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float uyN = (e < 3) ? uyc.v[(e + 1) & 3] : uyn;
+        const float div = uxe.v[e] - uxc.v[e] + uyN - uyc.v[e];  // VectorField.pde:61-62
+        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lwv + lev + lsv + lnv);
+        const float pcv = pc.v[e] + shift, pwv = pw.v[e] + shift, pev = pe.v[e] + shift;
+        const float psv = ((e > 0) ? pc.v[(e + 3) & 3] : psl) + shift, pnv = ((e < 3) ? pc.v[(e + 1) & 3] : pnr) + shift;
+        const float ap = pcv * diag + pwv * lwv + pev * lev + psv * lsv + pnv * lnv;  // PoissonMatrix.pde:57-61
+        o.r0.v[e] = div - ap;
+        d4[e] = o.r0.v[e] * iv.v[e];  // MG.pde:80
+      }
+      o.pc = pc;
+      o.psl = psl;
+      o.pnr = pnr;
+      H4_D4(R_, c4) = d4;
+      if (c4 == 0) H4_D1(R_, 0) = d4[0];  // d.setBC(): ghosts mirror the adjacent interior cell
+      if (c4 == CPR - 1) H4_D1(R_, m_ + 1) = d4[3];
+      if (R_ == 1 || R_ == n_) {
+        const int Rg_ = (R_ == 1) ? 0 : n_ + 1;
+        H4_D4(Rg_, c4) = d4;
+        if (c4 == 0) H4_D1(Rg_, 0) = d4[0];
+        if (c4 == CPR - 1) H4_D1(Rg_, m_ + 1) = d4[3];
+      }
+    }
+    return o;
+  };
+  // ---- step 2 on row G_: p, r of the row; returns the row's residuals for the restriction ----
+  auto step2 = [&](int G_, const Row &c) {
+    F4 ro;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ro.v[e] = 0.f;
+    if (on) {
+      const unsigned kb = 4u * (unsigned)(G_ * m + j);
+      const bool sp = (G_ >= sp_i0) && (G_ <= sp_i1);
+      F4 lw, le, ls;
+      float ln4;
+      if (sp) {
+        lw = ld4b(lxp, kb);
+        le = ld4b(lxp, kb + mb);
+        ls = ld4b(lyp, kb);
+        ln4 = ld1b(lyp, kb + 16u);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw.v[e] = le.v[e] = ls.v[e] = cu;
+        ln4 = cu;
+      }
+      const f4a dc = H4_D4(G_, c4), dw = H4_D4(G_ - 1, c4), de = H4_D4(G_ + 1, c4);
+      const float dl = H4_D1(G_, j - 1), dr = H4_D1(G_, j + 4);
+      const float d6[6] = {dl, dc[0], dc[1], dc[2], dc[3], dr};
+      F4 xo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lwv = lw.v[e], lev = le.v[e], lsv = ls.v[e], lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
+        const float diag = -(lwv + lev + lsv + lnv);
+        const float d = d6[1 + e];
+        const float ad = d * diag + dw[e] * lwv + de[e] * lev + d6[e] * lsv + d6[2 + e] * lnv;  // PoissonMatrix.pde:57-61
+        ro.v[e] = c.r0.v[e] - ad;                                                              // MG.pde:96
+        xo.v[e] = (c.pc.v[e] + shift) + d;                                                     // MG.pde:95
+      }
+      st4b(pout, kb, xo);
+      st4b(r, kb, ro);
+      // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
+      if (c4 == 0) st1b(pout, kb - 4u, (c.psl + shift) + d6[1]);
+      if (c4 == CPR - 1) st1b(pout, kb + 16u, (c.pnr + shift) + d6[4]);
+      if (G_ == 1 || G_ == n_) {
+        const unsigned kg = 4u * (unsigned)(((G_ == 1) ? 0 : (n - 1)) * m + j);
+        const F4 pg = ld4b(pin, kg);
+        F4 xg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xg.v[e] = (pg.v[e] + shift) + d6[1 + e];
+        st4b(pout, kg, xg);
+        if (c4 == 0) st1b(pout, kg - 4u, (ld1b(pin, kg - 4u) + shift) + d6[1]);
+        if (c4 == CPR - 1) st1b(pout, kg + 16u, (ld1b(pin, kg + 16u) + shift) + d6[4]);
+      }
+    }
+    return ro;
+  };
+  (void)step1(i_first - 1, (i_first - 1 > 1 ? i_first - 1 : 1), i_first - 1);  // the row above the run: its d only
+  Row cA = step1(i_first, i_first, d_hi), cB = step1(i_first + 1, i_first, d_hi);
+  asm volatile("" ::: "memory");
+  for (int g = i_first; g <= i_last; g += 2) {
+    const Row nA = step1(g + 2, g + 2, d_hi), nB = step1(g + 3, g + 2, d_hi);
+    // lanes read below what OTHER lanes of the wave have just stored: program order must survive the optimiser; in
+    // hardware the LDS operations of a wave execute in order
+    asm volatile("" ::: "memory");
+    const F4 ra = step2(g, cA), rb = step2(g + 1, cB);
+    if (on) {  // restrict (MG.pde:124-137): sum of the 2x2 children in the reference order
+      const int ci = (g - 1) / 2 + 1, cj = 2 * c4 + 1;
+      float two[2];
+      two[0] = ra.v[0] + ra.v[1] + rb.v[0] + rb.v[1];
+      two[1] = ra.v[2] + ra.v[3] + rb.v[2] + rb.v[3];
+      __builtin_memcpy((char *)r1 + 4u * (unsigned)(ci * m1 + cj), two, 8);
+    }
+    asm volatile("" ::: "memory");
+    cA = nA;
+    cB = nB;
+  }
+#undef H4_D4
+#undef H4_D1
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // The descending leg of a COARSE level (mg_down_fused<false, true>: d = r*inv; d.setBC; x = 0 + d; r -= A d;
 // r_c = restrict(r), MG.pde:69-70 with MG.pde:56,80,90-97,124-137) as FOUR INDEPENDENT ROW PIPELINES without a workgroup
@@ -2495,7 +2683,7 @@ __device__ __host__ __forceinline__ int down3_lds_floats(int m) {
   const int m_ = m - 2;
   return 4 * (down3_ns(m_) * (m_ + 4) + 8) + 8;
 }
-__device__ inline void down_v3c(const StepParams &P, const Lv &L0, const Lv &L1, float *lds) {
+__device__ AFC_DOWN_ATTR void down_v3c(const StepParams &P, const Lv &L0, const Lv &L1, float *lds) {
   const int n = uni(L0.n), m = uni(L0.m), n_ = n - 2, m_ = m - 2;
   const int CPR = m_ >> 2, PT = m_ + 4, RPI = down3_rpi(m_), NS = down3_ns(m_);
   const LevelDesc &D = *L0.desc;
@@ -2788,7 +2976,7 @@ __device__ inline void bottom_gs_wave(const BLv &L) {
 #undef BG_F
 }
 
-__device__ inline void mg_bottom(const StepParams &P, size_t e, int LB, float *lds, ProfT &pf) {
+__device__ AFC_BOT_ATTR void mg_bottom(const StepParams &P, size_t e, int LB, float *lds, ProfT &pf) {
   const int kc = P.nlev - 1;
   const int tid = threadIdx.x;
   const unsigned base = (lds_addr(lds) + 15u) & ~15u;
@@ -2937,6 +3125,8 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       if (l == 0 && iter == 1 && fused_head) {
         if (F.m == 130 && ((F.n - 2) & 7) == 0 && uni(P.head_v3) && !(AFC_DBG_OF(P) & 2048))
           head_v3(P, L0, Cc, ux, uy, pin, shift, lds);
+        else if (H0 != 16 && uni(P.head_v4) && head4_shape_ok(F.n, F.m) && !(AFC_DBG_OF(P) & 2048))
+          head_v4(P, L0, Cc, ux, uy, pin, shift, lds);  // (H0 != 16: only the instantiations for grids wider than 128 columns carry it)
         else
           mg_down_fused<true, false>(P, L0, Cc, ux, uy, pin, shift, lds);
       } else if (((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) {
@@ -3053,7 +3243,7 @@ __device__ inline void setbc_rows(const StepParams &P, float *ux, float *uy, flo
 // p' is NOT materialised: p stays as the solver left it and s is returned as the env's pending
 // shift; every reader of p (next solve's head, force, probes, field export) forms p+s itself --
 // the same float32 addition the reference's plusEq performs, so the bits are identical.
-__device__ inline void project_tail_v2(const bool HEUN, const StepParams &P, float *lds, const float *__restrict__ p,
+__device__ AFC_TAIL_ATTR void project_tail_v2(const bool HEUN, const StepParams &P, float *lds, const float *__restrict__ p,
                                        float shift, float *vx,
                                        float *vy, const float *__restrict__ ox, const float *__restrict__ oy,
                                        float *ax, float *ay, const bool fold) {

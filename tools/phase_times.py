@@ -20,15 +20,15 @@ def main():
     build.build()
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    z = None
-    wake = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "wake_res16_re100.npz")
-    if res == 16 and os.path.exists(wake):
-        z = np.load(wake)
+    # the committed start state of the grid (developed wake / the reference's init.bdim) and its Reynolds number
+    gold = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+    name, Re = {16: ("wake_res16_re100.npz", 100), 32: ("wake_res32_re400.npz", 400), 24: ("init_bdim_res24.npz", 500)}.get(res, (None, 100))
+    z = np.load(os.path.join(gold, name)) if name and os.path.exists(os.path.join(gold, name)) else None
     rng = np.random.default_rng(0)
     xi = (5 * rng.uniform(-1, 1, (E, 2))).astype(np.float32)
     ts = []
     for st in STOPS:
-        g = env.AFCEnv(num_envs=E, resolution=res, reynolds=100, dbg=st << 12)
+        g = env.AFCEnv(num_envs=E, resolution=res, reynolds=Re, dbg=st << 12)
         if z is not None:
             g.set_reset_state(z["u"], z["v"], z["p"])
             g.reset()
