@@ -3,7 +3,6 @@
 // fails with AFC_ENODEV when no HIP device is usable.
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -170,6 +169,7 @@ struct afc_env {
   int io_space = AFC_MEM_HOST;
   int E = 0;
   std::vector<void *> allocs;
+  bool slab_shared = false;  // development: the state slab belongs to another instance (AFC_SLAB_PTR)
   char *arena = nullptr;  // one allocation for all the small device buffers (tables shared by the envs, scalars, staging)
   size_t arena_size = 0, arena_off = 0;
   float *rs_u = nullptr, *rs_v = nullptr, *rs_p = nullptr;  // reset state (device)
@@ -554,48 +554,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     const int mode = am ? atoi(am) : 1;
     const size_t stag = as ? (size_t)atol(as) : 0;
     const size_t fsz = ((E * P.Ns + 64 + 63) / 64) * 64 + stag, csz = E * (size_t)P.Cs;
-    if (mode == 2) {  // experiment: every field its own allocation, the best 11 of 3 x 11 candidates by the streaming probe
-      std::vector<std::pair<float, float *>> cand;
-      hipEvent_t e0, e1;
-      (void)hipEventCreate(&e0);
-      (void)hipEventCreate(&e1);
-      const size_t n4 = fsz / 8;
-      for (int t = 0; t < 33 && !rc; ++t) {
-        void *q = nullptr;
-        if (hipMalloc(&q, fsz * sizeof(float)) != hipSuccess) {
-          (void)hipGetLastError();
-          break;
-        }
-        (void)hipMemsetAsync(q, 0, fsz * sizeof(float), nullptr);
-        float best = 1e30f;
-        for (int r = 0; r < 4; ++r) {
-          (void)hipEventRecord(e0, nullptr);
-          hipLaunchKernelGGL(k_copy_f4<false>, dim3(2048), dim3(256), 0, nullptr, (const f4v *)q, (f4v *)q + n4, n4);
-          (void)hipEventRecord(e1, nullptr);
-          (void)hipEventSynchronize(e1);
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, e0, e1);
-          if (r > 0 && ms < best) best = ms;
-        }
-        cand.push_back({(float)(2.0 * 16.0 * (double)n4 / (best * 1e-3) / 1e9), static_cast<float *>(q)});
-      }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-      std::sort(cand.begin(), cand.end(), [](const std::pair<float, float *> &x, const std::pair<float, float *> &y) { return x.first > y.first; });
-      if (cand.size() < 11) rc = fail(AFC_EHIP, "hipMalloc");
-      for (size_t t = 0; t < cand.size(); ++t) {
-        if (getenv("AFC_PRINT_ALLOC")) fprintf(stderr, "afc_create: field candidate %p %.0f GB/s\n", (void *)cand[t].second, cand[t].first);
-        if (t < 11 && !rc) {
-          env->allocs.push_back(cand[t].second);
-          (void)hipMemset(cand[t].second, 0, fsz * sizeof(float));
-          *fields[t] = (AFC_AS1 float *)cand[t].second;
-        } else {
-          (void)hipFree(cand[t].second);
-        }
-      }
-      if (!rc) rc = dev_alloc(env, &P.coarse, csz);
-      if (!rc && hipMemset(G(P.coarse), 0, csz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
-    } else if (mode == 0) {
+    if (mode == 0) {
       for (AFC_AS1 float **f : fields) {
         if (!rc) rc = dev_alloc(env, f, fsz);
         if (!rc && hipMemset(G(*f), 0, fsz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
@@ -604,16 +563,25 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       if (!rc && hipMemset(G(P.coarse), 0, csz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
     } else {
       float *slab = nullptr;
-      const size_t total = 11 * fsz + csz;
+      const size_t scz = ((E * sizeof(EnvScalars) + 255) / 256) * 64;  // the per-env scalars, in floats, at the end of the slab
+      const size_t total = 11 * fsz + csz + scz;
+      // development (tools/ab_inproc.py --share-slab): an instance adopts the slab of another instance of the same shape,
+      // so that builds are compared on the SAME memory (placements of the fast kind still differ by +-0.5 %)
+      const char *sp = getenv("AFC_SLAB_PTR");
+      if (sp && *sp) {
+        slab = reinterpret_cast<float *>(strtoull(sp, nullptr, 0));
+        env->slab_shared = true;
+      }
       // PLACEMENT.  Where the driver puts a buffer of this size decides what it streams at: the same copy kernel runs
       // 4-5 % apart between 1.7 GB allocations of one process, the step kernel 6-7 % (bimodal, stable to 0.1 % per
-      // allocation; translation misses are nil either way: tools/ab_inproc.py, tools/scratch/alloc_probe.py).  Large
+      // allocation; translation misses are nil either way: tools/ab_inproc.py, tools/alloc_probe.py).  Large
       // batches therefore take the best of a few candidate allocations by a streaming probe (a copy of one half of
       // the buffer onto the other, ~0.5 ms each) and give the others back.  AFC_PLACEMENT_TRIALS=1 switches it off.
       const char *pt = getenv("AFC_PLACEMENT_TRIALS");
-      int trials = pt ? atoi(pt) : 12;  // at most; the search stops early once a fast candidate stands out (below)
-      if (total * sizeof(float) < ((size_t)256 << 20) || trials < 1) trials = 1;
-      if (trials > 16) trials = 16;
+      int trials = pt ? atoi(pt) : 16;  // at most; the search stops early once a fast candidate stands out (below)
+      if (slab) trials = 0;
+      if (!slab && (total * sizeof(float) < ((size_t)256 << 20) || trials < 1)) trials = 1;
+      if (trials > 32) trials = 32;
       if (!rc && trials > 1) {
         std::vector<float *> cand;
         std::vector<float> rate;
@@ -670,14 +638,22 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       }
       if (!rc) {
         if (getenv("AFC_PRINT_ALLOC")) fprintf(stderr, "afc_create: state slab %p, %zu bytes\n", (void *)slab, total * sizeof(float));
+        {
+          char buf[32];
+          snprintf(buf, sizeof buf, "%p", (void *)slab);
+          setenv("AFC_LAST_SLAB", buf, 1);  // read back by tools/ab_inproc.py --share-slab
+        }
+        P.sc = (AFC_AS1 EnvScalars *)(slab + 11 * fsz + csz);
         size_t k = 0;
         for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + (k++) * fsz);
         P.coarse = (AFC_AS1 float *)(slab + 11 * fsz);
       }
     }
   }
-  if (!rc) rc = dev_alloc(env, &P.sc, E);
-  if (!rc && hipMemset(G(P.sc), 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  if (!rc && !P.sc) {  // (separate allocations: AFC_ALLOC_MODE=0)
+    rc = dev_alloc(env, &P.sc, E);
+    if (!rc && hipMemset(G(P.sc), 0, E * sizeof(EnvScalars)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+  }
   if (!rc) rc = dev_alloc(env, &env->rs_u, (size_t)P.Ns);
   if (!rc) rc = dev_alloc(env, &env->rs_v, (size_t)P.Ns);
   if (!rc) rc = dev_alloc(env, &env->rs_p, (size_t)P.Ns);

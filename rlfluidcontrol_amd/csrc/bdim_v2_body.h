@@ -9,6 +9,10 @@
 
 // Inlining of the phases (experiment hooks, build with AFC_EXTRA_FLAGS=-DAFC_ADV_ATTR=__noinline__ ...): `inline` leaves
 // the decision to the compiler, which inlines every phase into the step kernels (one register allocation for all).
+// Measured on the same memory (tools/ab_inproc.py --share-slab, 1024 envs 256x128, ms per launch): everything inline
+// 26.240; projection tail outlined 25.999 (-0.9 %); solve head outlined 26.151; both 26.081; advection + head + tail
+// 26.020; up-leg / bottom / coarse down-legs outlined: +18 %.  The projection tail is the one
+// phase that ships as a function of its own.
 #ifndef AFC_ADV_ATTR
 #define AFC_ADV_ATTR inline
 #endif
@@ -16,7 +20,7 @@
 #define AFC_HEAD_ATTR inline
 #endif
 #ifndef AFC_TAIL_ATTR
-#define AFC_TAIL_ATTR inline
+#define AFC_TAIL_ATTR __noinline__
 #endif
 #ifndef AFC_UP_ATTR
 #define AFC_UP_ATTR inline
@@ -1403,6 +1407,35 @@ __device__ inline void gs_rb_stage(const Lv &L, const float *rr, float *dr, int 
 }
 #endif
 
+// The three workgroup reductions that end the finest up-leg (r.r and sum(x) in double, max|r|) in ONE pass: the tree of
+// block_sum_d / block_max_f (t += t + s for s = 128 ... 1) with the same operands in the same order -- so the same
+// bits --, its two levels that cross waves through LDS and the six inside wave 0 through lane shuffles: 5 workgroup
+// barriers instead of 30.  stage: >= 2.6 KB of LDS nobody else is using.
+__device__ __forceinline__ void block_reduce3(double &a, double &b, float &c, float *stage) {
+  const int t = threadIdx.x;
+  double *sa = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(stage) + 7) & ~(uintptr_t)7), *sb = sa + 128;
+  float *sc = reinterpret_cast<float *>(sb + 128);
+  if (t >= 128) sa[t - 128] = a, sb[t - 128] = b, sc[t - 128] = c;
+  __syncthreads();
+  if (t < 128) a += sa[t], b += sb[t], c = jmax(c, sc[t]);
+  __syncthreads();
+  if (t >= 64 && t < 128) sa[t - 64] = a, sb[t - 64] = b, sc[t - 64] = c;
+  __syncthreads();
+  if (t < 64) {
+    a += sa[t], b += sb[t], c = jmax(c, sc[t]);
+#pragma unroll
+    for (int s_ = 32; s_ > 0; s_ >>= 1) {
+      a += __shfl_down(a, s_);
+      b += __shfl_down(b, s_);
+      c = jmax(c, __shfl_down(c, s_));
+    }
+    if (t == 0) sa[0] = a, sb[0] = b, sc[0] = c;
+  }
+  __syncthreads();
+  a = sa[0], b = sb[0], c = sc[0];
+  __syncthreads();
+}
+
 // One call = everything a level does on the way up (MG.pde:73-76 seen from the level itself):
 //   HASC:  d = prolongate(coarse.x); increment()            [x += d, r -= A d]
 //   then   smooth(4): d = r*inv; 4 Gauss-Seidel sweeps; d.setBC(); increment()
@@ -1602,9 +1635,10 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   }
   __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
   if (need_r && rmode != 2) {
-    *rr_out = uni((float)block_sum_d(rr_part, sm));
-    *linf_out = uni(block_max_f(linf, sm));
-    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+    block_reduce3(rr_part, xs_part, linf, lds);  // (the rings are dead: the phase-boundary barrier above); -0.22 % on the same memory
+    *rr_out = uni((float)rr_part);
+    *linf_out = uni(linf);
+    if (xsum_out) *xsum_out = uni((float)xs_part);
   }
 }
 
@@ -3109,7 +3143,7 @@ __device__ AFC_BOT_ATTR void mg_bottom(const StepParams &P, size_t e, int LB, fl
 template <int H0 = 16>
 __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const Lv &L0, const float *ux, const float *uy,
                                   const float *pin, float shift, double *sm, float *linf_out, float *xsum_out,
-                                  ProfT &pf, float *lds, bool fused_head = true) {
+                                  ProfT &pf, float *lds, bool fused_head = true, bool hard = false) {
   const int kc = P.nlev - 1;
   // levels LB .. kc run out of LDS (mg_bottom) where the host found room for them; LB > kc: level by level as before
   const int LB = (!AFC_RB && uni(P.bottom_lb) >= 2 && !(AFC_DBG_OF(P) & 128)) ? uni(P.bottom_lb) : kc + 1;
@@ -3169,7 +3203,10 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       if (l > 0 && down3 && down3_shape_ok(F.n, F.m) && ((F.m - 2) & 3) == 0 && ((F.n - 2) & 1) == 0) F.r = F.d;  // where down_v3c left r
       // the finest level's new r is only read again by a further V-cycle (or by the sequential
       // inner product of the parity mode): normally it is not written back at all
-      const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2);
+      // hard: the caller expects this solve to need a second V-cycle (the predictor's solve of the first sim-step after an
+      // action change -- where ALL second cycles of the bench workload occur, 4.7 % of the envs per agent step): its
+      // residual is written back right away, so that the stragglers of a launch are spared the replay of the level
+      const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2) && !hard;
       // two strips per round / two marching waves where the level is big enough and its rings fit the LDS region
       // two strips per round / two marching waves (mg_up_smooth2): bit-exact, but measured SLOWER than the single march
       // (DESIGN.md): kept as an experiment of the diagnostic instantiation only (dbg bit 8 switches it on)
@@ -3223,7 +3260,7 @@ __device__ inline void setbc_rows(const StepParams &P, float *ux, float *uy, flo
     uy[(n - 1) * m + j] = uy[(n - 2) * m + j];
   }
   lds_barrier();
-  if (threadIdx.x == 0) {  // Field.pde:302-318 order
+  if (threadIdx.x == 0) {  // Field.pde:302-318 order (one wave adding the row through v_readlane: 0.25 % SLOWER on the same memory)
     float s = 0;
     for (int j = 1; j < m - 1; ++j) s += rowbuf[j];
     s /= (float)(m - 2);
@@ -3350,13 +3387,13 @@ template <int C, int TAG = 0>
 __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e, float *vx, float *vy,
                                  const float *pin, float *pout,
                                  float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
-                                 float *linf_out, ProfT &pf, float *lds) {
+                                 float *linf_out, ProfT &pf, float *lds, bool hard = false) {
   const size_t eo = e * (size_t)P.Ns;
   Lv L0 = make_level(P, e, 0);
   L0.x = pout;
   L0.d = G(P.u0y) + eo;  // scratch of the straightforward kernels (rare 2nd MG iteration)
   float xsum = 0.f;
-  const int iters = mg_solve_v2<up_strip_h(C)>(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds);
+  const int iters = mg_solve_v2<up_strip_h(C)>(P, e, L0, vx, vy, pin, *shift_io, sm, linf_out, &xsum, pf, lds, true, hard);
   if (pf.stop >= 3 && pf.stop <= 5) return iters;
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
@@ -3407,7 +3444,7 @@ __device__ __forceinline__ void eval_force_wave(const StepParams &P, const float
 // k_agent_step and allocated without their register cap)
 template <int C>
 __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
-                                   ShBcast *sh, float *lds) {
+                                   ShBcast *sh, float *lds, const bool first_after_action = false) {
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
   const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
@@ -3453,7 +3490,8 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
 #if AFC_DIAG
     if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
 #endif
-    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds);
+    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds,
+                                 first_after_action && half == 0);
     if (pf.stop >= 3 && pf.stop <= 6) return;
 #if AFC_DIAG
     if (pf.stop) pf.stop += 8 * half;

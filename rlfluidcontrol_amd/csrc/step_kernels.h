@@ -11,6 +11,12 @@
 #include "bdim_v2.h"
 #include "step_launch.h"
 
+#ifdef AFC_NO_HARD_HINT  // experiment: every solve with the lazy residual (tools/ab_inproc.py)
+#define AFC_HARD_HINT(x) false
+#else
+#define AFC_HARD_HINT(x) (x)
+#endif
+
 namespace {
 
 using afc::EnvScalars;
@@ -26,11 +32,11 @@ using afc::StepParams;
 // bdim_v2.h): 0 = shipped, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; cfg.gs_mode = 1).
 template <int CPL, int MODE>
 __device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
-                                              double *sm, afc::ShBcast *sh, float *lds) {
+                                              double *sm, afc::ShBcast *sh, float *lds, bool first_after_action = false) {
   if constexpr (CPL == 0)
     afc::sim_step(P, e, a, b, sm, sh);
   else
-    afc::AFC_MODE_NS::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds);
+    afc::AFC_MODE_NS::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds, first_after_action);
 }
 
 template <int CPL, int MODE>
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
     if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
-    step_dispatch<CPL, MODE>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn);
+    step_dispatch<CPL, MODE>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn, AFC_HARD_HINT(steps == 0));  // the action is new in the first step
     ++steps;
     if (threadIdx.x == 0) {
       s.t += P.dt / P.resolution;

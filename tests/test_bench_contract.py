@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed round-3 line has every field of the contract, its numbers are
+"""The bench line the driver parses: the committed line of the current round has every field of the contract, its numbers are
 consistent with each other, and bench.py's argument parser keeps the contract's flags (CPU only, nothing is launched)."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_bench.json")) as f:
         return json.loads(f.read().strip().split("\n")[-1])
 
 
@@ -78,10 +78,14 @@ def test_committed_traffic_figure_belongs_to_the_shipped_kernel_sources():
 
 
 def test_other_baseline_configs_are_named_not_custom():
-    for f, name in (("r3_bench_cfg4.json", "BASELINE.json configs[3]"), ("r3_bench_native.json", "reference-native 384x192")):
+    """the secondary workloads are lines of driver grade too: named, with cpu_baseline and (where the committed PMC
+    figure belongs to the same kernel sources) roofline.traffic, >= 64 timed agent steps"""
+    for f, name in (("r4_bench_cfg4.json", "BASELINE.json configs[3]"), ("r4_bench_native.json", "reference-native 384x192")):
         with open(os.path.join(ROOT, "profiles", f)) as fh:
             d = json.loads(fh.read().strip().split("\n")[-1])
-        assert d["config"]["workload"].startswith(name) and d["roofline"]["frac"] > 0.2 and d["diverged_envs"] == 0
-    with open(os.path.join(ROOT, "profiles", "r3_bench_perfmode.json")) as fh:
+        assert d["config"]["workload"].startswith(name) and d["roofline"]["frac"] > 0.35 and d["diverged_envs"] == 0
+        assert d["steps"] >= 64 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
+        assert d["roofline"]["traffic"] is None or 1.0 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.5
+    with open(os.path.join(ROOT, "profiles", "r4_bench_perfmode.json")) as fh:
         d = json.loads(fh.read().strip().split("\n")[-1])
     assert "PERF MODE" in d["config"]["workload"] and d["config"]["gs_order"].startswith("red-black")

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--per-block", type=int, default=6)
     ap.add_argument("--action-scale", type=float, default=1.0, help="actions are U(-s, s)^2 (0: no actuation, all envs alike)")
+    ap.add_argument("--share-slab", action="store_true",
+                    help="every instance adopts the state slab of the first one (AFC_SLAB_PTR): builds are compared on the "
+                         "SAME memory -- they must be bit-identical builds, the simulation simply continues from launch to launch")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import torch
@@ -47,8 +50,14 @@ def main():
         a.libs[k] = lib + (":" + evs if evs else "")
         for kv in filter(None, evs.split(",")):
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
+        if a.share_slab and k > 0:
+            import ctypes
+            libc = ctypes.CDLL(None)
+            libc.getenv.restype = ctypes.c_char_p
+            os.environ["AFC_SLAB_PTR"] = libc.getenv(b"AFC_LAST_SLAB").decode()
         m = load_env_module(str(k), lib)
         g = m.AFCEnv(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, device=0)
+        os.environ.pop("AFC_SLAB_PTR", None)
         if z is not None and z["u"].shape == (g.n, g.m):
             g.set_reset_state(z["u"], z["v"], z["p"])
         g.use_device_io(stream.cuda_stream)
@@ -93,9 +102,10 @@ def main():
         v = np.array(ms[k])
         print("%-40s %8.3f ms per launch (min %.3f, max %.3f over %d blocks)  %+.2f %% time vs first"
               % (os.path.basename(lib), v.mean(), v.min(), v.max(), len(v), 100.0 * (v.mean() / base - 1.0)))
-    for k, g in enumerate(envs):
+    for k, g in enumerate(envs if not a.share_slab else envs[:1]):
         h = g.mg_histogram()
         print("  env %d: multigrid iterations per solve, all launches: %s" % (k, {i + 1: int(v) for i, v in enumerate(h) if v}))
+    for g in reversed(envs):  # (a shared slab belongs to the first instance: closed last)
         g.close()
 
 

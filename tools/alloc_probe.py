@@ -1,3 +1,5 @@
+"""Streaming rate of ten 1.7 GB allocations of one process (a copy of one half onto the other, three rounds): the rate
+is a property of the allocation -- 4-5 % between them, stable per allocation.  python tools/alloc_probe.py"""
 import torch, time
 dev = torch.device("cuda", 0)
 N = 1708919552 // 4

@@ -3,7 +3,7 @@ the step kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM presc
   FETCH_SIZE, WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
   (16 B/lane) coalesced streaming reads -> doubled (an upper estimate for our mixed 4/8/16-byte
   loads; WRITE_SIZE is exact for 16 B/lane stores).  Separate passes (TCC has 4 slots).
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [res]"""
 import csv
 import json
 import os
@@ -26,7 +26,8 @@ out = {"kernel": "k_agent_step", "fetch_size_kib_raw": fetch_kib, "write_size_ki
        "fetch_bytes_corrected_x2": 2 * fetch_kib * 1024, "write_bytes": write_kib * 1024,
        "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
        "kernel_src_sha16": kernel_source_hash(),
-       "note": "steady launches (16 sim-steps x 1024 envs, 256x128); FETCH_SIZE doubled per the gfx950 correction "
+       "grid": "%dx%d" % (16 * int(sys.argv[4]), 8 * int(sys.argv[4])) if len(sys.argv) > 4 else "256x128",
+       "note": "steady launches (16 sim-steps x 1024 envs); FETCH_SIZE doubled per the gfx950 correction "
                "(upper estimate: part of our loads are 4- and 8-byte wide, for which the counter is uncalibrated)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)

@@ -1,42 +1,59 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ on a GPU box (run through gpurun from the repo root):
-#   tools/refresh_profiles.sh <tag>      e.g. r3   -> gpurun_out/profiles_<tag>/
-# bench lines (headline, cfg4, reference-native, perf mode), rocprofv3 kernel stats of the headline command, steady
-# launch average, HBM traffic (two PMC passes), SQ counters, per-phase time / traffic / counters, per-level profile,
-# march micro-benchmark.
-TAG=${1:-r3}
+#   tools/refresh_profiles.sh <tag>      e.g. r4   -> gpurun_out/profiles_<tag>/
+# For each of the three measured grids (BASELINE configs[1] 256x128, configs[3] 512x256, reference-native 384x192): the
+# bench line with cpu_baseline and roofline.traffic (HBM bytes per launch from two PMC passes on the same sources), and the
+# lock-step phase times.  For the headline grid also: rocprofv3 kernel stats, steady launch average, SQ / LDS counters,
+# per-phase counters and traffic, per-level profile, the perf-mode line with its counters, the march micro-benchmark and
+# the memory-placement evidence (tools/ab_inproc.py).
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 S="--no-cpu-baseline --steps 8 --warmup 2 --repeats 1"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- $B $S > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- $B $S > /dev/null 2>&1
+# ---- HBM traffic per launch, every grid (separate passes: TCC has 4 counter slots) ----
+for g in "16 100 " "32 400 _cfg4" "24 500 _native"; do
+  set -- $g; res=$1; re=$2; sfx=$3
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f$sfx -- $B $S --res $res --reynolds $re > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w$sfx -- $B $S --res $res --reynolds $re > /dev/null 2>&1
+  (cd $R; python3 tools/pmc_traffic.py $(find $O/pmc_f$sfx -name "*counter_collection.csv" | head -1) $(find $O/pmc_w$sfx -name "*counter_collection.csv" | head -1) $O/${TAG}_hbm_traffic$sfx.json "${res}" > /dev/null
+   cp $O/${TAG}_hbm_traffic$sfx.json $R/profiles/${TAG}_hbm_traffic$sfx.json)   # bench.py quotes it as roofline.traffic (same kernel sources only)
+done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/pmc_sq -- $B $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR --output-format csv -d $O/pmc_sq2 -- $B $S > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $O/pmc_perf -- $B $S --gs-mode 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pt_f -- python3 $R/tools/phase_traffic.py run > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pt_w -- python3 $R/tools/phase_traffic.py run > /dev/null 2>&1
 cd $R
-python3 tools/pmc_traffic.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/${TAG}_hbm_traffic.json > /dev/null
-cp $O/${TAG}_hbm_traffic.json $R/profiles/${TAG}_hbm_traffic.json   # bench.py quotes it as roofline.traffic (same kernel sources only)
+# ---- bench lines (the driver's command for the headline; >= 64 agent steps x 3 passes and cpu_baseline for every grid) ----
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
-timeout 600 python bench.py --no-cpu-baseline --res 32 --reynolds 400 --steps 16 > $O/${TAG}_bench_cfg4.json 2>> $O/bench.err
-timeout 600 python bench.py --no-cpu-baseline --res 24 --reynolds 500 --steps 32 > $O/${TAG}_bench_native.json 2>> $O/bench.err
+timeout 1200 python bench.py --res 32 --reynolds 400 > $O/${TAG}_bench_cfg4.json 2>> $O/bench.err
+timeout 900 python bench.py --res 24 --reynolds 500 > $O/${TAG}_bench_native.json 2>> $O/bench.err
 timeout 600 python bench.py --no-cpu-baseline --gs-mode 1 > $O/${TAG}_bench_perfmode.json 2>> $O/bench.err
 (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --no-cpu-baseline --steps 16 --repeats 2 > $O/${TAG}_bench_under_rocprof.json 2>/dev/null)
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
 python3 tools/steady_kernel_avg.py $(find $O/stats -name "*kernel_trace.csv" | head -1) > $O/${TAG}_steady_launch.txt
 python3 tools/pmc_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.json
 python3 tools/pmc_summary.py $O/pmc_sq2 > $O/${TAG}_sq_counters2.json
+python3 tools/pmc_summary.py $O/pmc_perf > $O/${TAG}_sq_counters_perfmode.json
 python3 tools/phase_traffic.py report $O/pt_f $O/pt_w > $O/${TAG}_phase_traffic.txt
-timeout 300 python tools/phase_times.py 1024 16 > $O/${TAG}_phase_times_E1024.txt 2>&1
-timeout 300 python tools/phase_times.py 1 16 > $O/${TAG}_phase_times_E1.txt 2>&1
-timeout 300 python tools/level_profile.py 1024 8 > $O/${TAG}_level_profile_E1024.txt 2>&1
-timeout 300 python tools/level_profile.py 1 8 > $O/${TAG}_level_profile_E1.txt 2>&1
-rm -rf $O/stats $O/pmc_f $O/pmc_w $O/pmc_sq $O/pmc_sq2 $O/pt_f $O/pt_w
+for g in "16 " "32 _cfg4" "24 _native"; do
+  set -- $g
+  timeout 400 python tools/phase_times.py 1024 $1 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1024$2.txt
+done
+timeout 300 python tools/phase_times.py 1 16 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1.txt
+timeout 300 python tools/level_profile.py 1024 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1024.txt
+timeout 300 python tools/level_profile.py 1 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1.txt
+rm -rf $O/stats $O/pmc_f* $O/pmc_w* $O/pmc_sq $O/pmc_sq2 $O/pmc_perf $O/pt_f $O/pt_w
 bash tools/phase_counters.sh $O/phase_counters > /dev/null 2>&1
 cat $O/phase_counters/p1.txt $O/phase_counters/p2.txt $O/phase_counters/p3.txt > $O/${TAG}_phase_counters.txt
 rm -rf $O/phase_counters
+# ---- memory placement: the same library, env instances with and without the placement search, launches interleaved
+# (two processes: instances of one process compete for the fast placements) ----
+L=rlfluidcontrol_amd/libafc_env.so
+(echo "AFC_PLACEMENT_TRIALS=1 (first allocation taken), six instances of one process:"; python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 2>&1 | grep "ms per launch";
+ echo "default (best of up to 16 candidate allocations by the streaming probe), three instances of one process:"; AFC_PRINT_ALLOC=1 python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L $L $L 2>&1 | grep "ms per launch\|candidate") > $O/${TAG}_placement.txt
 (cd tools; for kp in 36 42; do for nw in 1 2 4; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DAFC_ONLY_MODE=0 -DNW=$nw -DAFC_KPAD_FORCE=$kp march_bench.hip -o /tmp/mb 2>/dev/null && echo "pitch pad $kp, marching waves per workgroup $nw" && /tmp/mb 0 | grep -v "workgroups=   1"; done; done) > $O/${TAG}_march_bench.txt 2>&1
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt
