@@ -397,7 +397,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     const size_t tile = 2 * ((size_t)(P.adv_rows + 4) * sf.m + 4) + 8;  // advdif_v2 (16-byte aligned tiles)
     // mg_up_smooth's rings on the finest level, with the strip height of this grid's kernel instantiation (coarser
     // levels have at most half the columns and always fit 16-row strips)
-    const size_t rings = (size_t)afc::prod::gs_lds_floats(sf.m, afc::prod::up_strip_h(((sf.m - 2) + 63) / 64)) + 64;
+    // (perf mode keeps its 12-row strips of eight shifted stages in 24-row rings on every grid: a wide grid then runs
+    // fewer workgroups per CU, as in round 3)
+    const size_t rings = (size_t)afc::prod::gs_lds_floats(sf.m, cfg->gs_mode == 1 ? 16 : afc::prod::up_strip_h(((sf.m - 2) + 63) / 64)) + 64;
     size_t fl = tile > rings ? tile : rings;
     // multi-wave smoother: both rings of every level live in the same region; with four workgroups per CU a
     // workgroup may use 40 KB of LDS in all (static part ~2.3 KB)

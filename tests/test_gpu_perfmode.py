@@ -160,8 +160,10 @@ def test_perf_mode_solver_is_red_black_multigrid(envmod, res, Re):
     written out in numpy -- on the 128x64 hierarchy (even widths down to 4x2) and on the 384x192 one, whose coarsest
     levels are 14x8 -> 6x3 cells: ODD width, where one colour has a column more than the other (the
     kernel used to leave the last column of such a level unrelaxed).  The kernel sweeps strip by strip with the
-    stages shifted by a row each, which is the same red-black iteration cell for cell: iterates agree to round-off
-    (2e-5 of max|x| allowed), iteration counts exactly."""
+    stages shifted by a row each, which is the same red-black iteration cell for cell, with the reference's operation
+    order inside every update: the solutions are BIT-IDENTICAL, iteration counts equal.  (This test also caught an LDS
+    overflow of the perf-mode rings on the wide grids: reads beyond a workgroup's LDS return 0, so the step-level
+    tolerance tests still passed while the solver needed 16 V-cycles for what takes 2.)"""
     g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re, gs_mode=1)
     levels = []
     for l in range(g.num_levels):
@@ -191,5 +193,5 @@ def test_perf_mode_solver_is_red_black_multigrid(envmod, res, Re):
     assert itg == it and it < 20, (itg, it)
     scale = float(np.abs(x).max())
     print("perf-mode MG vs numpy red-black: res %d, %d iterations, max|dx| %.3g of max|x| %.3g" % (res, it, float(np.abs(xg - x).max()), scale))
-    assert float(np.abs(xg - x).max()) <= 2e-5 * scale, (float(np.abs(xg - x).max()), scale)
+    assert np.array_equal(xg, x), (float(np.abs(xg - x).max()), scale)
     g.close()
