@@ -25,7 +25,10 @@ def test_step_kernels_keep_four_workgroups_per_cu():
         if "ILi0E" not in n:  # optimised kernels: static LDS small, the dynamic part (tiles / rings) gets the rest of 40 KB
             assert v["group_segment_fixed_size"] <= 3 * 1024, (n, v)
             # spill budget (bytes per lane): what is spilled sits outside the innermost loops (tools/loop_scan.py)
-            assert v["private_segment_fixed_size"] <= (640 if "k_agent_step" in n else 1024), (n, v)
+            # (the projection tail is a function of its own since round 4: its callee-saved registers are part of the figure;
+            # the diagnostic instantiation, which nobody times, gets a little more room)
+            diag = n.split("ELi")[-1].startswith("1E")
+            assert v["private_segment_fixed_size"] <= ((768 if diag else 640) if "k_agent_step" in n else 1024), (n, v)
     shipped = {n: v for n, v in step.items() if n.split("ELi")[-1].startswith("0E") and "ILi0E" not in n}
     assert len(shipped) == 8
     for n, v in shipped.items():
