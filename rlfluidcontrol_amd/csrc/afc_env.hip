@@ -3,6 +3,7 @@
 // fails with AFC_ENODEV when no HIP device is usable.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -437,9 +438,55 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   UP(delx); UP(dely); UP(del1x); UP(del1y); UP(wnxx); UP(wnxy); UP(wnyx); UP(wnyy); UP(cx); UP(cy);
   UP(w1x); UP(w2x); UP(ry1x); UP(ry2x); UP(w1y); UP(w2y); UP(rx1y); UP(rx2y);
   UP(seg_l); UP(seg_nx); UP(seg_ny);
-  UP(band_x); UP(band_y);
+  // band cells within reach of a control cylinder (a non-zero weight at the cell or at one of its four neighbours)
+  // first: the others skip the body-velocity part of the forcing (ub == +0 there, exactly)
+  std::vector<int> bxs = sf.band_x, bys = sf.band_y;
+  auto reach_x = [&](int k) {
+    for (int o : {0, sf.m, -sf.m, 1, -1})
+      if (sf.w1x[k + o] != 0.f || sf.w2x[k + o] != 0.f) return true;
+    return false;
+  };
+  auto reach_y = [&](int k) {
+    for (int o : {0, sf.m, -sf.m, 1, -1})
+      if (sf.w1y[k + o] != 0.f || sf.w2y[k + o] != 0.f) return true;
+    return false;
+  };
+  P.nflag_x = (int)(std::stable_partition(bxs.begin(), bxs.end(), reach_x) - bxs.begin());
+  P.nflag_y = (int)(std::stable_partition(bys.begin(), bys.end(), reach_y) - bys.begin());
+  {
+    const std::vector<int> *bx_ = &bxs, *by_ = &bys;
+    if (!rc) rc = dev_upload(env, &P.band_x, *bx_);
+    if (!rc) rc = dev_upload(env, &P.band_y, *by_);
+  }
   P.nband_x = (int)sf.band_x.size();
   P.nband_y = (int)sf.band_y.size();
+  {  // the compact tables
+    const size_t nb = bxs.size() > bys.size() ? bxs.size() : bys.size();
+    const int stride = (int)((nb + 63) / 64 * 64) + 64;
+    std::vector<float> tx((size_t)24 * stride, 0.f), ty((size_t)24 * stride, 0.f);
+    const int offs[5] = {0, sf.m, -sf.m, 1, -1};
+    for (size_t q = 0; q < bxs.size(); ++q) {
+      const int k = bxs[q];
+      tx[q] = sf.delx[k], tx[stride + q] = sf.del1x[k], tx[2 * (size_t)stride + q] = sf.wnxx[k], tx[3 * (size_t)stride + q] = sf.wnyx[k];
+      for (int p_ = 0; p_ < 5; ++p_) {
+        const int kk = k + offs[p_];
+        float *t4 = tx.data() + (size_t)(4 + 4 * p_) * stride + q;
+        t4[0] = sf.w1x[kk], t4[stride] = sf.w2x[kk], t4[2 * (size_t)stride] = sf.ry1x[kk], t4[3 * (size_t)stride] = sf.ry2x[kk];
+      }
+    }
+    for (size_t q = 0; q < bys.size(); ++q) {
+      const int k = bys[q];
+      ty[q] = sf.dely[k], ty[stride + q] = sf.del1y[k], ty[2 * (size_t)stride + q] = sf.wnxy[k], ty[3 * (size_t)stride + q] = sf.wnyy[k];
+      for (int p_ = 0; p_ < 5; ++p_) {
+        const int kk = k + offs[p_];
+        float *t4 = ty.data() + (size_t)(4 + 4 * p_) * stride + q;
+        t4[0] = sf.w1y[kk], t4[stride] = sf.w2y[kk], t4[2 * (size_t)stride] = sf.rx1y[kk], t4[3 * (size_t)stride] = sf.rx2y[kk];
+      }
+    }
+    P.band_stride = (P.impl != 0) ? stride : 0;
+    if (!rc) rc = dev_upload(env, &P.band_tab_x, tx);
+    if (!rc) rc = dev_upload(env, &P.band_tab_y, ty);
+  }
   {  // wall columns folded into the row stores: the forcing band (and the cells it reads) must stay clear of the walls
     bool clear = true;
     for (const std::vector<int> *b : {&sf.band_x, &sf.band_y})

@@ -115,6 +115,11 @@ struct StepParams {
   const AFC_AS1 float *bottom_rec;  // its cell records {lw, le, ls, ln, inv, 0, 0, 0}, levels bottom_lb .. nlev-1 back to back
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
+  // compact band tables (forcing_cell_tab): 24 arrays of band_stride floats per component, slot q = band cell q:
+  // del, del1, wnx, wny, then for the cell and its neighbours +m, -m, +1, -1: w1, w2, lever arm 1, lever arm 2
+  const AFC_AS1 float *band_tab_x, *band_tab_y;
+  int band_stride;       // 0: no tables (the gather form)
+  int nflag_x, nflag_y;  // band cells within reach of a control cylinder come first in band_x / band_y
 };
 
 // ---- PApplet float helpers (same semantics as Java's) ----

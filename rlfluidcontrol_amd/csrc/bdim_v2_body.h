@@ -683,6 +683,44 @@ __device__ __forceinline__ float forcing_y_cell(const StepParams &P, const float
   const float g = 0.5f * (G(P.wnxy)[k] * (dE - dW) + G(P.wnyy)[k] * (dN - dS));
   return un + G(P.del1y)[k] * g;
 }
+// The same cell from the COMPACT BAND TABLE (StepParams::band_tab_x / _y, built by the host): everything the cell
+// needs from the env-shared coefficient arrays -- del, del1, the two wall normals, and for the cell and its four
+// neighbours the two control cylinders' weights and lever arms -- sits at the cell's own slot q of 24 arrays of `stride`
+// floats, so that a wave reads it with coalesced loads (64 slots = 256 contiguous bytes per instruction) instead of 25
+// gathers of 64 different cache lines each; only the five values of F itself are still gathered.  As gathers the phase
+// was bound by the texture addresser: 375 fully divergent load instructions per env and half-step, 50 us per half-step
+// with four envs per CU against 9 us for one env alone.  Cells out of reach of the control cylinders (weights exactly
+// +0 at all five positions: ub == +0 there) come after the `nflag` cells within reach and skip the 20 loads.
+// Same operands, same order, same bits as forcing_x_cell / forcing_y_cell.
+template <bool YC>
+__device__ __forceinline__ float forcing_cell_tab(const float *__restrict__ tab, int stride, int q, bool reach,
+                                                  const float *__restrict__ f, int k, int m, float dphi1, float dphi2,
+                                                  float dt) {
+  const float del = tab[q], del1 = tab[stride + q], wnx = tab[2 * stride + q], wny = tab[3 * stride + q];
+  float ub[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // centre, +m, -m, +1, -1
+  if (reach) {
+#pragma unroll
+    for (int p_ = 0; p_ < 5; ++p_) {
+      const float *t4 = tab + (4 + 4 * p_) * stride + q;
+      const float w1 = t4[0], w2 = t4[stride], r1 = t4[2 * stride], r2 = t4[3 * stride];
+      float v = 0.f;
+      v += 0.f;  // main cylinder (ub_x_at / ub_y_at)
+      v += ((YC ? (0.f + r1 * dphi1) : (0.f - r1 * dphi1)) / dt) * w1;
+      v += ((YC ? (0.f + r2 * dphi2) : (0.f - r2 * dphi2)) / dt) * w2;
+      ub[p_] = v;
+    }
+  }
+  // (the five values of F: staging the bodies' neighbourhood of F in LDS first, coalesced, and gathering from there is
+  // bit-exact and changes nothing -- 25.340 against 25.322 ms per launch on the same memory)
+  const float R = f[k];
+  const float un = del * R - ub[0] * (del + (-1.f));
+  const float dE = f[k + m] - ub[1];
+  const float dW = f[k - m] - ub[2];
+  const float dN = f[k + 1] - ub[3];
+  const float dS = f[k - 1] - ub[4];
+  const float g = 0.5f * (wnx * (dE - dW) + wny * (dN - dS));
+  return un + del1 * g;
+}
 __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, float *stage, float dphi1,
                                     float dphi2) {
   // stage: LDS, nband_x + nband_y floats (the host checks that the region holds them)
@@ -690,14 +728,26 @@ __device__ inline void forcing_band(const StepParams &P, float *fx, float *fy, f
   const int *bandx = G(P.band_x), *bandy = G(P.band_y);
   const int tid = threadIdx.x;
   const int nmax = nbx > nby ? nbx : nby;
+  const bool tabs = uni(P.band_stride) != 0 && !(AFC_DBG_OF(P) & 32);  // dbg bit 5: the gather form
+  const float *tx = uni(G(P.band_tab_x)), *ty = uni(G(P.band_tab_y));
+  const int stride = uni(P.band_stride), nfx = uni(P.nflag_x), nfy = uni(P.nflag_y);
+  const float dt = uni(P.dt);
   lds_barrier();  // the region's previous user (the advection rings) is done
   for (int base = 0; base < nmax; base += 2 * kThreads) {
     const int q0 = base + tid, q1 = q0 + kThreads;
     const bool x0 = q0 < nbx, x1 = q1 < nbx, y0 = q0 < nby, y1 = q1 < nby;
     const int kx0 = x0 ? bandx[q0] : m + 1, kx1 = x1 ? bandx[q1] : m + 1;  // an idle slot reads (and ignores) cell [1][1]
     const int ky0 = y0 ? bandy[q0] : m + 1, ky1 = y1 ? bandy[q1] : m + 1;
-    const float ux0 = forcing_x_cell(P, fx, kx0, m, dphi1, dphi2), ux1 = forcing_x_cell(P, fx, kx1, m, dphi1, dphi2);
-    const float uy0 = forcing_y_cell(P, fy, ky0, m, dphi1, dphi2), uy1 = forcing_y_cell(P, fy, ky1, m, dphi1, dphi2);
+    float ux0, ux1, uy0, uy1;
+    if (tabs) {  // (idle slots read slot 0 of the table)
+      ux0 = forcing_cell_tab<false>(tx, stride, x0 ? q0 : 0, x0 && q0 < nfx, fx, kx0, m, dphi1, dphi2, dt);
+      ux1 = forcing_cell_tab<false>(tx, stride, x1 ? q1 : 0, x1 && q1 < nfx, fx, kx1, m, dphi1, dphi2, dt);
+      uy0 = forcing_cell_tab<true>(ty, stride, y0 ? q0 : 0, y0 && q0 < nfy, fy, ky0, m, dphi1, dphi2, dt);
+      uy1 = forcing_cell_tab<true>(ty, stride, y1 ? q1 : 0, y1 && q1 < nfy, fy, ky1, m, dphi1, dphi2, dt);
+    } else {
+      ux0 = forcing_x_cell(P, fx, kx0, m, dphi1, dphi2), ux1 = forcing_x_cell(P, fx, kx1, m, dphi1, dphi2);
+      uy0 = forcing_y_cell(P, fy, ky0, m, dphi1, dphi2), uy1 = forcing_y_cell(P, fy, ky1, m, dphi1, dphi2);
+    }
     if (x0) stage[q0] = ux0;
     if (x1) stage[q1] = ux1;
     if (y0) stage[nbx + q0] = uy0;

@@ -243,6 +243,7 @@ PATHS = [(4, "all-waves smoother"), (15 << 16, "CU populations taking turns"), (
          (128, "bottom of the V-cycle level by level through global memory instead of out of LDS (mg_bottom)"),
          (256, "up-legs with two strips per round and two marching waves, r streamed from global memory (mg_up_smooth2)"),
          (16, "coarse down-legs in blocks with workgroup barriers (mg_down_fused) instead of per-wave row pipelines (down_v3c)"),
+         (32, "forcing band through gathers from the full coefficient arrays instead of the compact band tables"),
          (-(1 << 31), "u.setBC() as its own pass with strided column accesses instead of folded into the row stores")]
 
 
