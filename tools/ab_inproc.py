@@ -50,6 +50,8 @@ def main():
         a.libs[k] = lib + (":" + evs if evs else "")
         for kv in filter(None, evs.split(",")):
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
+        if a.share_slab and k == 0:
+            os.environ["AFC_EXPORT_SLAB"] = "1"
         if a.share_slab and k > 0:
             import ctypes
             libc = ctypes.CDLL(None)

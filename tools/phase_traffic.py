@@ -1,6 +1,7 @@
 """HBM bytes per phase of one sim-step, by differencing launches that leave the step early.
-Run twice under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE); then `phase_traffic.py report <dirF> <dirW>`.
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out_f -- python3 tools/phase_traffic.py run"""
+Run twice under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE); then `phase_traffic.py report <dirF> <dirW> [res]`.
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out_f -- python3 tools/phase_traffic.py run [res]
+res = 16 (256x128, Re 100; default), 24 (384x192, Re 500, init.bdim) or 32 (512x256, Re 400)."""
 import csv
 import glob
 import os
@@ -14,13 +15,17 @@ REP = 3
 E = 1024
 
 
-def run():
+GRIDS = {16: ("wake_res16_re100.npz", 100), 24: ("init_bdim_res24.npz", 500), 32: ("wake_res32_re400.npz", 400)}
+
+
+def run(res=16):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from rlfluidcontrol_amd import build, env
     build.build()
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "wake_res16_re100.npz"))
+    name, Re = GRIDS[res]
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", name))
     for st in STOPS:
-        g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=st << 12)
+        g = env.AFCEnv(num_envs=E, resolution=res, reynolds=Re, dbg=st << 12)
         g.set_reset_state(z["u"], z["v"], z["p"])
         g.reset()
         xi = np.zeros((E, 2), np.float32)
@@ -44,10 +49,10 @@ def series(d, counter):
     return [min(vals[i * REP:(i + 1) * REP][1:]) for i in range(len(STOPS))]  # skip each env's first launch
 
 
-def report(df, dw):
+def report(df, dw, res=16):
     f = [2 * 1024 * v for v in series(df, "FETCH_SIZE")]  # gfx950: x2, KiB
     w = [1024 * v for v in series(dw, "WRITE_SIZE")]
-    cells = E * 256 * 128
+    cells = E * (16 * res) * (8 * res)
     prev_f = prev_w = 0.0
     print("%-34s %10s %10s   (floats per cell)" % ("phase", "read", "write"))
     for i, st in enumerate(STOPS):
@@ -98,10 +103,10 @@ def report_counters(d):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run()
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 16)
     elif sys.argv[1] == "insts":
         report_insts(sys.argv[2])
     elif sys.argv[1] == "counters":
         report_counters(sys.argv[2])
     else:
-        report(sys.argv[2], sys.argv[3])
+        report(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 16)

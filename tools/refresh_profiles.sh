@@ -24,8 +24,11 @@ done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/pmc_sq -- $B $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR --output-format csv -d $O/pmc_sq2 -- $B $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $O/pmc_perf -- $B $S --gs-mode 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pt_f -- python3 $R/tools/phase_traffic.py run > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pt_w -- python3 $R/tools/phase_traffic.py run > /dev/null 2>&1
+for g in "16 " "32 _cfg4" "24 _native"; do
+  set -- $g
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pt_f$2 -- python3 $R/tools/phase_traffic.py run $1 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pt_w$2 -- python3 $R/tools/phase_traffic.py run $1 > /dev/null 2>&1
+done
 cd $R
 # ---- bench lines (the driver's command for the headline; >= 64 agent steps x 3 passes and cpu_baseline for every grid) ----
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
@@ -38,7 +41,9 @@ python3 tools/steady_kernel_avg.py $(find $O/stats -name "*kernel_trace.csv" | h
 python3 tools/pmc_summary.py $O/pmc_sq > $O/${TAG}_sq_counters.json
 python3 tools/pmc_summary.py $O/pmc_sq2 > $O/${TAG}_sq_counters2.json
 python3 tools/pmc_summary.py $O/pmc_perf > $O/${TAG}_sq_counters_perfmode.json
-python3 tools/phase_traffic.py report $O/pt_f $O/pt_w > $O/${TAG}_phase_traffic.txt
+python3 tools/phase_traffic.py report $O/pt_f $O/pt_w 16 > $O/${TAG}_phase_traffic.txt
+python3 tools/phase_traffic.py report $O/pt_f_cfg4 $O/pt_w_cfg4 32 > $O/${TAG}_phase_traffic_cfg4.txt
+python3 tools/phase_traffic.py report $O/pt_f_native $O/pt_w_native 24 > $O/${TAG}_phase_traffic_native.txt
 for g in "16 " "32 _cfg4" "24 _native"; do
   set -- $g
   timeout 400 python tools/phase_times.py 1024 $1 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1024$2.txt
@@ -46,7 +51,7 @@ done
 timeout 300 python tools/phase_times.py 1 16 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1.txt
 timeout 300 python tools/level_profile.py 1024 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1024.txt
 timeout 300 python tools/level_profile.py 1 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1.txt
-rm -rf $O/stats $O/pmc_f* $O/pmc_w* $O/pmc_sq $O/pmc_sq2 $O/pmc_perf $O/pt_f $O/pt_w
+rm -rf $O/stats $O/pmc_f* $O/pmc_w* $O/pmc_sq $O/pmc_sq2 $O/pmc_perf $O/pt_f* $O/pt_w*
 bash tools/phase_counters.sh $O/phase_counters > /dev/null 2>&1
 cat $O/phase_counters/p1.txt $O/phase_counters/p2.txt $O/phase_counters/p3.txt > $O/${TAG}_phase_counters.txt
 rm -rf $O/phase_counters
