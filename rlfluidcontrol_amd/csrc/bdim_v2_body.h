@@ -57,6 +57,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 typedef __attribute__((address_space(3))) float lds_f;  // explicit LDS pointers: ds_* accesses, 32-bit addresses
 typedef __attribute__((address_space(3))) int lds_i;
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two consecutive floats, 4-byte aligned
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+typedef __attribute__((address_space(3))) f4a lds_f4;
 typedef __attribute__((address_space(3))) f2u lds_f2;
 // One Gauss-Seidel update of the march up to the subtraction of r, as the nine instructions it needs, in the
 // reference's order (MG.pde:84-88): ((dW*lw + dE*le) + dS*ls) + dN*ln - r with dW = lane-1's previous result
@@ -809,7 +811,7 @@ __device__ __host__ constexpr int up_strip_h(int cpl) { return cpl <= 2 ? 16 : (
 // ring rows for strips of H rows: the march has rows I0-4 .. I0+H in flight and the exit reads one row further up
 __device__ __host__ constexpr int up_ring_rows(int H) { return H == 16 ? 24 : H + 6; }
 __device__ __host__ __forceinline__ int gs_lds_floats(int m, int H = 16) {
-  return AFC_KPAD + (2 * up_ring_rows(H) + 2) * ring_pitch(m) + 3 * AFC_KPAD;
+  return AFC_KPAD + (2 * up_ring_rows(H) + 2) * ring_pitch(m) + 3 * AFC_KPAD + 8;
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
@@ -1181,6 +1183,7 @@ struct UpGeom {
   bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
   bool update_x = true;  // false: replay that only materialises r
   float *rglob = nullptr;  // mg_up_smooth2: r after the prolongation increment lives HERE (global), not in an LDS ring
+  bool al16 = false;       // ring column 1 sits on a 16-byte boundary: the chunk accesses of fill / exit are 128-bit
 };
 struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
   F4 r;
@@ -1266,6 +1269,12 @@ __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int
     if (g <= n_) store4u(U.rglob + g * m + j, rv);
 #pragma unroll
     for (int e = 0; e < 4; ++e) U.dr[sl + e] = dv.v[e];
+  } else if (U.al16) {  // one ds_write_b128 per ring instead of four stride-4 dword stores (4-way bank conflicts)
+    f4a r4, d4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r4[e] = rv.v[e], d4[e] = dv.v[e];
+    *(lds_f4 *)(lds_f *)(U.rr + sl) = r4;
+    *(lds_f4 *)(lds_f *)(U.dr + sl) = d4;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1320,8 +1329,16 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
     dp[3] = in.a2;
   }
   float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
+  if (U.al16) {
+    const f4a dc4 = *(const lds_f4 *)(lds_f *)(dr + sl);
+    d6[0] = dr[sl - 1];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
+    for (int e = 0; e < 4; ++e) d6[1 + e] = dc4[e];
+    d6[5] = dr[sl + 4];
+  } else {
+#pragma unroll
+    for (int b = 0; b < 6; ++b) d6[b] = dr[sl - 1 + b];
+  }
   if (c4 == 0) d6[0] = d6[1];
   if (c4 == CPR - 1) d6[5] = d6[4];
   F4 xn;
@@ -1346,13 +1363,24 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
       }
     }
     F4 rn;
+    float dwv[4], dev[4], rov[4];
+    if (U.al16) {
+      const f4a w4 = *(const lds_f4 *)(lds_f *)dwp, e4 = *(const lds_f4 *)(lds_f *)dep;
+      f4a o4 = {0.f, 0.f, 0.f, 0.f};
+      if (!U.rglob) o4 = *(const lds_f4 *)(lds_f *)(rr + sl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dwv[e] = w4[e], dev[e] = e4[e], rov[e] = o4[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dwv[e] = dwp[e], dev[e] = dep[e], rov[e] = U.rglob ? 0.f : rr[sl + e];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
       const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
       const float d = d6[1 + e];
-      const float rold = U.rglob ? in.r.v[e] : rr[sl + e];
-      rn.v[e] = rold - (d * diag + dwp[e] * lw.v[e] + dep[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
+      const float rold = U.rglob ? in.r.v[e] : rov[e];
+      rn.v[e] = rold - (d * diag + dwv[e] * lw.v[e] + dev[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
       const float pr = rn.v[e] * rn.v[e];
       rr_part += (double)pr;
       linf = jmax(linf, jabs(rn.v[e]));
@@ -1506,7 +1534,9 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   constexpr int H = HS, NR = up_ring_rows(HS);
 #endif
   const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));  // diagnostics: phase marks for the level with n rows
-  float *rr = lds + kPad, *dr = rr + NR * PW + kPad, *zrow = dr + NR * PW + kPad, *dummy = zrow + PW + kPad;
+  // the whole layout sits 3 floats in: ring column 1 (the first interior one) falls on a 16-byte boundary, so a thread's
+  // 4-column chunk is one 128-bit LDS access in fill / exit (PW, kPad and NR * PW are multiples of 4 floats)
+  float *rr = lds + kPad + 3 + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2), *dr = rr + NR * PW + kPad, *zrow = dr + NR * PW + kPad, *dummy = zrow + PW + kPad;
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
@@ -1519,6 +1549,7 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   const DescU du = desc_u(D);
   UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
   U.NR = NR;
+  U.al16 = true;
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
   // a thread keeps its 4-column chunk and walks down the rows of its group: no integer division in the strip loops
@@ -2167,8 +2198,6 @@ __device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &C
 // setBC mirror written into its ghost columns and rows, so that the patches read their 4x6 window of d without any
 // clamping, computed once per cell.  Threads keep their 4-column chunk c4 and walk down rows / row pairs: no division
 // inside the loops.
-typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
-typedef __attribute__((address_space(3))) f4a lds_f4;
 template <bool RESID, bool XZ>
 __device__ inline void mg_down_fused(const StepParams &P, const Lv &L0, const Lv &L1, const float *__restrict__ ux,
                                      const float *__restrict__ uy, const float *__restrict__ pin, float shift,
