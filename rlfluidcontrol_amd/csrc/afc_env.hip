@@ -597,22 +597,25 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     // same library ran 7 % apart between env instances whose arrays came from separate hipMalloc calls (same box, same
     // process, launches interleaved: tools/ab_inproc.py) -- where the driver happens to place a dozen 140 MB buffers
     // decides how the streams of a phase fall on the memory channels / translation fragments.
-    // + 64 floats per field: the row staging copies of advdif_v3 read up to 3 floats past the end of a row.
+    // + 64 floats per field: the row staging copies of advdif_v3 read up to 3 floats past the end of a row -- and ONE float
+    // in front of row 0 (a left-hand tile's ring index 0 is "column -1"): kFront floats of padding precede the first field.
     // Development: AFC_ALLOC_MODE=0 restores separate allocations.
     const char *am = getenv("AFC_ALLOC_MODE");
     const int mode = am ? atoi(am) : 1;
     const size_t fsz = ((E * P.Ns + 64 + 63) / 64) * 64, csz = E * (size_t)P.Cs;
+    constexpr size_t kFront = 64;
     if (mode == 0) {
       for (AFC_AS1 float **f : fields) {
-        if (!rc) rc = dev_alloc(env, f, fsz);
-        if (!rc && hipMemset(G(*f), 0, fsz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+        if (!rc) rc = dev_alloc(env, f, fsz + kFront);
+        if (!rc && hipMemset(G(*f), 0, (fsz + kFront) * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
+        if (!rc) *f += kFront;
       }
       if (!rc) rc = dev_alloc(env, &P.coarse, csz);
       if (!rc && hipMemset(G(P.coarse), 0, csz * sizeof(float)) != hipSuccess) rc = fail(AFC_EHIP, "hipMemset");
     } else {
       float *slab = nullptr;
       const size_t scz = ((E * sizeof(EnvScalars) + 255) / 256) * 64;  // the per-env scalars, in floats, at the end of the slab
-      const size_t total = 11 * fsz + csz + scz;
+      const size_t total = kFront + 11 * fsz + csz + scz;
       // development (tools/ab_inproc.py --share-slab): an instance adopts the slab of another instance of the same shape,
       // so that builds are compared on the SAME memory (placements of the fast kind still differ by +-0.5 %)
       const char *sp = getenv("AFC_SLAB_PTR");
@@ -697,10 +700,10 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           snprintf(buf, sizeof buf, "%p", (void *)slab);
           setenv("AFC_LAST_SLAB", buf, 1);
         }
-        P.sc = (AFC_AS1 EnvScalars *)(slab + 11 * fsz + csz);
+        P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + 11 * fsz + csz);
         size_t k = 0;
-        for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + (k++) * fsz);
-        P.coarse = (AFC_AS1 float *)(slab + 11 * fsz);
+        for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + kFront + (k++) * fsz);
+        P.coarse = (AFC_AS1 float *)(slab + kFront + 11 * fsz);
       }
     }
   }

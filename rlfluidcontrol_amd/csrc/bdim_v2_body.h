@@ -60,6 +60,8 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two conse
 typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
 typedef __attribute__((address_space(3))) f4a lds_f4;
 typedef __attribute__((address_space(3))) f2u lds_f2;
+typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef __attribute__((address_space(3))) f2a8 lds_f2a;
 // One Gauss-Seidel update of the march up to the subtraction of r, as the nine instructions it needs, in the
 // reference's order (MG.pde:84-88): ((dW*lw + dE*le) + dS*ls) + dN*ln - r with dW = lane-1's previous result
 // (DPP row_shr:1 folded INTO the multiply; lanes 0,16,32,48 have no DPP source and keep `w*lw`, the value from the
@@ -505,7 +507,12 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   const int ncol = (m_ > 64 * C) ? 2 : 1, nrow = 4 / ncol;
   const int tcol = (ncol == 2) ? (wave & 1) : 0, trow = (ncol == 2) ? (wave >> 1) : wave;
   const int W = m_ / ncol, lanes_on = W / C;
-  const int jlo = 1 + tcol * W, c0 = tcol ? jlo - 2 : 0;  // first interior column of the tile; column at ring index 0
+  // first interior column of the tile; column at ring index 0: always jlo - 2, so that the lane's first cell sits at
+  // ring index 2 + C*lane -- for C = 2 every pair of columns (j0 + 2k, j0 + 2k + 1) is one aligned 8-byte LDS read (as
+  // dword pairs at odd indices the reads of a wave hit every bank twice).  A left-hand tile's index 0 is "column -1":
+  // the float in front of the row (the previous row's wall / the previous env / the pad in front of the state slab),
+  // staged and never used.
+  const int jlo = 1 + tcol * W, c0 = jlo - 2;
   const int LQ = (W + 7) >> 2;                            // 16-byte pieces of a staged row (W + 4 columns)
   const int RPW = (n_ + nrow - 1) / nrow;
   const int i_first = 1 + trow * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
@@ -513,6 +520,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   const float nu = uni(P.nu), dt = uni(P.dt);
   const bool same = (bx == sx) && (by == sy);
   const int nb = same ? 0 : 2;  // base-row copies per iteration
+  const float *sxc = sx + c0, *syc = sy + c0, *bxc = bx + c0, *byc = by + c0;  // staging sources: column c0 of row 0
   if (i_first <= i_last) {
     const int r_hi = (i_last + 2 < n - 1) ? i_last + 2 : n - 1;  // last row this wave stages
     int r_next = i_first - 2, s_next = 0;  // next row to stage and its ring slot
@@ -520,9 +528,9 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   {                                                                                    \
     const unsigned ln_ = lane_fresh();                                                 \
     if (r_next >= 0 && r_next <= r_hi && ln_ < (unsigned)LQ) {                         \
-      const unsigned so_ = 4u * (unsigned)(r_next * m + c0) + 16u * ln_;               \
-      lds_dma16(sx, so_, ring + (unsigned)s_next * PRB);                               \
-      lds_dma16(sy, so_, ring + (unsigned)(s_next + NS) * PRB);                        \
+      const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                    \
+      lds_dma16(sxc, so_, ring + (unsigned)s_next * PRB);                              \
+      lds_dma16(syc, so_, ring + (unsigned)(s_next + NS) * PRB);                       \
     }                                                                                  \
     ++r_next;                                                                          \
     s_next = (s_next + 1 == NS) ? 0 : s_next + 1;                                      \
@@ -531,10 +539,10 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   {                                                                                    \
     const unsigned ln_ = lane_fresh();                                                 \
     if (ln_ < (unsigned)LQ) {                                                          \
-      const unsigned so_ = 4u * (unsigned)((row) * m + c0) + 16u * ln_;                \
+      const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
       const unsigned lb_ = ring + (unsigned)(2 * NS + 2 * ((row) & 1)) * PRB;          \
-      lds_dma16(bx, so_, lb_);                                                         \
-      lds_dma16(by, so_, lb_ + PRB);                                                   \
+      lds_dma16(bxc, so_, lb_);                                                        \
+      lds_dma16(byc, so_, lb_ + PRB);                                                  \
     }                                                                                  \
   }
     for (int q = 0; q < NS; ++q) ADV3_STAGE()  // rows i_first-2 .. i_first+4
@@ -567,8 +575,35 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
       const lds_f *r2 = (const lds_f *)(uintptr_t)(lo + (unsigned)s2 * PRB);
       const lds_f *r3 = (const lds_f *)(uintptr_t)(lo + (unsigned)s3 * PRB);
       const lds_f *r4 = (const lds_f *)(uintptr_t)(lo + (unsigned)s4 * PRB);
-      // (row pointer, column relative to the lane's first cell) -> both components
-#define XY(r, dj) f2{(r)[(dj)], (r)[YO + (dj)]}
+      // The values the row's stencils touch, by (ring row, column relative to the lane's first cell): row i columns
+      // -2 .. C+1 (-2 only for a right-hand tile's own south face), row i-1 columns 0 .. C (x: .. C-1), row i+1 columns
+      // -1 .. C-1 (y: from 0), row i+2 columns 0 .. C-1.  C = 2: aligned 8-byte reads (the lane's first cell is at an even
+      // ring index), single dwords for the odd ones out.
+      float X_r2[C + 4], Y_r2[C + 4], X_r1[C + 1], Y_r1[C + 1], X_r3[C + 1], Y_r3[C + 1], X_r4[C], Y_r4[C];
+      constexpr int O_r2 = 2, O_r1 = 0, O_r3 = 1, O_r4 = 0, O_r0 = 0;
+#define LDP(r, dj) (*(const lds_f2a *)((r) + (dj)))
+      if constexpr (C == 2) {
+#pragma unroll
+        for (int d = -2; d < C + 2; d += 2) {
+          const f2 a = LDP(r2, d), b = LDP(r2 + YO, d);
+          X_r2[d + 2] = a.x, X_r2[d + 3] = a.y, Y_r2[d + 2] = b.x, Y_r2[d + 3] = b.y;
+        }
+        const f2 a1 = LDP(r1, 0), b1 = LDP(r1 + YO, 0), a3 = LDP(r3, 0), b3 = LDP(r3 + YO, 0), a4 = LDP(r4, 0), b4 = LDP(r4 + YO, 0);
+        X_r1[0] = a1.x, X_r1[1] = a1.y, X_r1[C] = 0.f, Y_r1[0] = b1.x, Y_r1[1] = b1.y, Y_r1[C] = r1[YO + C];
+        X_r3[0] = r3[-1], X_r3[1] = a3.x, X_r3[2] = a3.y, Y_r3[0] = 0.f, Y_r3[1] = b3.x, Y_r3[2] = b3.y;
+        X_r4[0] = a4.x, X_r4[1] = a4.y, Y_r4[0] = b4.x, Y_r4[1] = b4.y;
+      } else {
+#pragma unroll
+        for (int d = -2; d < C + 2; ++d) X_r2[d + 2] = (d == -2 && !tcol) ? 0.f : r2[d], Y_r2[d + 2] = (d == -2 && !tcol) ? 0.f : r2[YO + d];
+#pragma unroll
+        for (int d = 0; d <= C; ++d) X_r1[d] = (d < C) ? r1[d] : 0.f, Y_r1[d] = r1[YO + d];
+#pragma unroll
+        for (int d = -1; d < C; ++d) X_r3[d + 1] = r3[d], Y_r3[d + 1] = (d >= 0) ? r3[YO + d] : 0.f;
+#pragma unroll
+        for (int d = 0; d < C; ++d) X_r4[d] = r4[d], Y_r4[d] = r4[YO + d];
+      }
+      // (ring row, column relative to the lane's first cell) -> both components
+#define XY(r, dj) f2{X_##r[(dj) + O_##r], Y_##r[(dj) + O_##r]}
       const bool rok = (i >= 2) && (i <= n - 2);  // row part of the fallback test for cells of row i
       const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
       float oxv[C], oyv[C];
@@ -582,18 +617,26 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
         const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
         ccv[e] = cc;
         if (t == 0) {  // the run's first row: its west face (afterwards = the previous row's east face)
-          const lds_f *r0 = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
+          const lds_f *r0p = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
+          float X_r0[C], Y_r0[C];
+          if constexpr (C == 2) {
+            const f2 a0 = LDP(r0p, 0), b0 = LDP(r0p + YO, 0);
+            X_r0[0] = a0.x, X_r0[1] = a0.y, Y_r0[0] = b0.x, Y_r0[1] = b0.y;
+          } else {
+#pragma unroll
+            for (int d = 0; d < C; ++d) X_r0[d] = r0p[d], Y_r0[d] = r0p[YO + d];
+          }
           const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
           const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});
           fE2[e] = uo * quick_face2(XY(r0, e), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);
         }
-        const f2 ue = 0.5f * (f2{ce.x, r3[e - 1]} + f2{cc.x, ce.x});
+        const f2 ue = 0.5f * (f2{ce.x, X_r3[e - 1 + O_r3]} + f2{cc.x, ce.x});
         fEn[e] = ue * quick_face2(cw, cc, ce, XY(r4, e), ue, rok ? mC : 0, rokE ? mC : 0);
         if (e == 0) {
           const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});
           fSw = vs * (0.5f * (cs + cc));
         }
-        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{r1[YO + e + 1], cn.y});
+        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{Y_r1[e + 1], cn.y});
         fNn[e] = vn * quick_face2(cs, cc, cn, XY(r2, e + 2), vn, rok ? mC : 0, rok ? mCN : 0);
         difv[e] = ce + cn - 4.f * cc + cw + cs;  // VectorField.pde:198-200
       }
@@ -601,7 +644,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
         const lmask mC = lanes_if((j0 - 1 >= 2) && (j0 - 1 <= m - 2));
         const lmask mCN = lanes_if((j0 >= 2) && (j0 <= m - 2));
         const f2 cc = XY(r2, -1), cn = XY(r2, 0), cs = XY(r2, -2);
-        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{r1[YO], cn.y});
+        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{Y_r1[0], cn.y});
         fSw = vn * quick_face2(cs, cc, cn, XY(r2, 1), vn, rok ? mC : 0, rok ? mCN : 0);
       }
 #undef XY
@@ -613,8 +656,13 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
         // iteration's copies) or by the prologue
         wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + ST : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
         const lds_f *bb = (const lds_f *)(uintptr_t)(lo + (unsigned)(2 * NS + 2 * (i & 1)) * PRB);
+        if constexpr (C == 2) {
+          const f2 ab = LDP(bb, 0), bb2 = LDP(bb + PR, 0);
+          basev[0] = f2{ab.x, bb2.x}, basev[1] = f2{ab.y, bb2.y};
+        } else {
 #pragma unroll
-        for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
+          for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < C; ++e) basev[e] = ccv[e];
@@ -650,6 +698,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
       s0 = s1;
     }
 #undef ADV3_STAGE
+#undef LDP
 #undef ADV3_BASE
   }
   __syncthreads();
