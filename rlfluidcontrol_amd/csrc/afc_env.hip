@@ -558,24 +558,23 @@ int afc_create(const afc_config *cfg, afc_env **out) {
                    (size_t)afc::prod::bottom_lds_floats(P.lev, P.nlev) * sizeof(float) <= env->lds_bytes) ? lb : 0;
   }
 
-  std::vector<float> brec;  // mg_bottom's record table: one 32-byte record per cell of the bottom levels
+  std::vector<float> brec;  // mg_bottom's table: per bottom level the planes CF {lw, le, ls, ln} | IR {inv, r = 0} | X = 0 | D = 0
   if (P.bottom_lb)
     for (int l = P.bottom_lb; l < P.nlev; ++l) {
       const int n = P.lev[l].n, m = P.lev[l].m, off = P.lev[l].coef_off;
-      for (int k = 0; k < afc::prod::bottom_cells4(P.lev[l]); ++k) {
-        float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (k < n * m) {
-          const int i = k / m, j = k % m;
-          if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
-            rec[0] = lx[off + k];
-            rec[1] = lx[off + k + m];
-            rec[2] = ly[off + k];
-            rec[3] = ly[off + k + 1];
-          }
-          rec[4] = inv[off + k];
+      const int c4 = afc::prod::bottom_cells4(P.lev[l]);
+      std::vector<float> lvl((size_t)8 * c4, 0.f);
+      for (int k = 0; k < n * m; ++k) {
+        const int i = k / m, j = k % m;
+        if (i >= 1 && i <= n - 2 && j >= 1 && j <= m - 2) {
+          lvl[4 * k + 0] = lx[off + k];
+          lvl[4 * k + 1] = lx[off + k + m];
+          lvl[4 * k + 2] = ly[off + k];
+          lvl[4 * k + 3] = ly[off + k + 1];
         }
-        brec.insert(brec.end(), rec, rec + 8);
+        lvl[(size_t)4 * c4 + 2 * k] = inv[off + k];
       }
+      brec.insert(brec.end(), lvl.begin(), lvl.end());
     }
   brec.insert(brec.end(), 64, 0.f);
   if (!rc) rc = dev_upload(env, &P.bottom_rec, brec);

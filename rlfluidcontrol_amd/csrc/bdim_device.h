@@ -112,7 +112,7 @@ struct StepParams {
   int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows
   int bc_fold;         // 1: the row-streaming passes store the wall columns of u themselves, setBC is row work only (setbc_rows)
-  const AFC_AS1 float *bottom_rec;  // its cell records {lw, le, ls, ln, inv, 0, 0, 0}, levels bottom_lb .. nlev-1 back to back
+  const AFC_AS1 float *bottom_rec;  // its table: per level the planes {lw, le, ls, ln} / {inv, 0} / 0 / 0 per cell, levels bottom_lb .. nlev-1 back to back
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;
   // compact band tables (forcing_cell_tab): 24 arrays of band_stride floats per component, slot q = band cell q:

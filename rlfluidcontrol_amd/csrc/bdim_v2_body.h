@@ -3006,9 +3006,9 @@ __device__ AFC_DOWN_ATTR void down_v3c(const StepParams &P, const Lv &L0, const 
 // 32x16 and below on the 16:8 grids, ~700 cells in all) cost next to nothing in arithmetic but, done level by level through
 // global memory, a dozen barrier-separated passes with a round trip each per level -- 200 us of the 1 750 us sim-step
 // at 1024 envs (profiles/r3_level_profile_E1024.txt).  Here everything those levels touch lives in LDS for the whole
-// sub-cycle, as one RECORD of eight floats per cell (ghost cells included):
-//     { lw, le, ls, ln | inv, r, x, d }      lw..ln = the four face coefficients of the cell, gathered by the host
-// The records of all bottom levels are one contiguous table in global memory (StepParams::bottom_rec, shared by all
+// sub-cycle, eight floats per cell (ghost cells included), per level in four planes (see BLv):
+//     { lw, le, ls, ln } | { inv, r } | x | d      lw..ln = the four face coefficients of the cell, gathered by the host
+// The planes of all bottom levels are one contiguous table in global memory (StepParams::bottom_rec, shared by all
 // envs, r = x = d = 0) that the workgroup copies into LDS with the LDS-DMA path: one round trip, no registers.
 //
 // The reference's whole-array operations (MG.pde:53-97, 124-152; the straightforward kernels of bdim_device.h are
@@ -3050,11 +3050,22 @@ __device__ __host__ __forceinline__ int bottom_lds_floats(const LevelDesc *lev, 
 struct BLv {      // a bottom level in LDS (everything wave-uniform)
   int n, m, n_, m_, cnt;
   unsigned rcp;   // ceil(2^16 / m): k / m == (k * rcp) >> 16 for k < 2048, m <= 18
-  unsigned rec;   // LDS byte address of the records (32 bytes per cell)
+  unsigned rec;   // LDS byte address of the level's planes: CF (16 bytes per cell) | IR (8) | X (4) | D (4)
+  unsigned ir, x, d;  // byte addresses of the IR, X and D planes
 };
+// The record's eight floats live in four PLANES per level (cells4 = the cell count rounded up to 4):
+//   CF  {lw, le, ls, ln} per cell | IR  {inv, r} per cell | X | D
+// so that what the lanes of a wave touch together lies together: as 32-byte records (round 3) every access of the passes
+// (consecutive cells) and of the sweeps (cells 1 - m apart) had a stride of a multiple of 8 dwords -- 8 lanes per bank,
+// 16 cycles for a dword access instead of 2, the LDS pipe as busy as the chain of dependent steps it was meant to feed.
 enum { BR_INV = 4, BR_R = 5, BR_X = 6, BR_D = 7 };  // record fields after the four coefficients
-#define B_REC4(L, k) (*(lds_f4 *)(uintptr_t)((L).rec + 32u * (unsigned)(k)))
-#define B_F(L, k, f) (*(lds_f *)(uintptr_t)((L).rec + 32u * (unsigned)(k) + 4u * (f)))
+template <int F>
+__device__ __forceinline__ unsigned b_addr(const BLv &L, unsigned k) {
+  static_assert(F >= BR_INV && F <= BR_D, "field");
+  return F == BR_INV ? L.ir + 8u * k : (F == BR_R ? L.ir + 8u * k + 4u : (F == BR_X ? L.x + 4u * k : L.d + 4u * k));
+}
+#define B_REC4(L, k) (*(lds_f4 *)(uintptr_t)((L).rec + 16u * (unsigned)(k)))
+#define B_F(L, k, f) (*(lds_f *)(uintptr_t)(b_addr<f>((L), (unsigned)(k))))
 __device__ __forceinline__ BLv bottom_level(const StepParams &P, int LB, int l, unsigned base) {
   unsigned off = 0;
   for (int q = LB; q < l; ++q) off += 32u * (unsigned)((uni(P.lev[q].n) * uni(P.lev[q].m) + 3) & ~3);
@@ -3066,6 +3077,10 @@ __device__ __forceinline__ BLv bottom_level(const StepParams &P, int LB, int l, 
   L.cnt = L.n * L.m;
   L.rcp = (65536u + (unsigned)L.m - 1u) / (unsigned)L.m;
   L.rec = base + off;
+  const unsigned c4 = (unsigned)((L.cnt + 3) & ~3);
+  L.ir = L.rec + 16u * c4;
+  L.x = L.rec + 24u * c4;
+  L.d = L.rec + 28u * c4;
   return L;
 }
 
@@ -3083,31 +3098,35 @@ __device__ __forceinline__ BLv bottom_level(const StepParams &P, int LB, int l, 
 constexpr int kLagB = 3;
 __device__ inline void bottom_gs_wave(const BLv &L) {
   const int lane = threadIdx.x & 63, s = lane >> 4, c = lane & 15;
-  const unsigned pitch = 32u * (unsigned)L.m;
+  const unsigned pitch = 4u * (unsigned)L.m;  // bytes per row of the D plane
   const unsigned n_ = (unsigned)L.n_;
   const int steps = L.n_ + L.m_ - 1 + 3 * kLagB;
   const int i0 = 1 - kLagB * s - c;                                 // the row of this lane at step 0
   unsigned im1 = (c < L.m_) ? (unsigned)(i0 - 1) : 0x40000000u;     // row - 1: rows 1 .. n_ are the active ones
-  const unsigned dummy = L.rec + 4u * BR_D;                         // d of the ghost corner (0, 0): never read
-  const float g0 = *(lds_f *)(uintptr_t)(L.rec + 32u * (unsigned)(c + 1) + 4u * BR_D);  // d of the ghost row above the column
+  const unsigned dummy = L.d;                                       // d of the ghost corner (0, 0): never read
+  const float g0 = *(lds_f *)(uintptr_t)(L.d + 4u * (unsigned)(c + 1));  // d of the ghost row above the column
 #define BG_F(a, o) (*(lds_f *)(uintptr_t)((a) + (o)))
   struct Ops {
     f4a cf;
     float iv, r, dE, dN, dS0;
   };
-  // operands of the step whose cell is right of record address a; an = the address one row further down
+  // The lane's ONE running address: d of the cell LEFT of its cell (kL = i*m + c; the cell itself is kL + 1), in the D
+  // plane.  The cell's coefficients and (inv, r) sit at 16 and 8 bytes per cell in their planes:
+  //   &CF[kL + 1] = 4 * a + kcf,   &IR[kL + 1] = 2 * a + kir     (a = L.d + 4 kL; unsigned wrap-around is fine)
+  const unsigned kcf = L.rec + 16u - 4u * L.d, kir = L.ir + 8u - 2u * L.d;
+  // operands of the step whose cell is right of address a; an = the address one row further down
   auto fetch = [&](unsigned a, unsigned an) {
     Ops o;
-    o.cf = *(lds_f4 *)(uintptr_t)(a + 32u);
-    const f2u sv = *(const lds_f2 *)(uintptr_t)(a + 32u + 4u * BR_INV);  // (inv, r)
+    o.cf = *(lds_f4 *)(uintptr_t)(4u * a + kcf);
+    const f2u sv = *(const lds_f2 *)(uintptr_t)(2u * a + kir);  // (inv, r)
     o.iv = sv.x;
     o.r = sv.y;
-    o.dS0 = BG_F(a, 4u * BR_D);
-    o.dN = BG_F(a, 64u + 4u * BR_D);
-    o.dE = BG_F(an, 32u + 4u * BR_D);
+    o.dS0 = BG_F(a, 0u);
+    o.dN = BG_F(a, 8u);
+    o.dE = BG_F(an, 4u);
     return o;
   };
-  unsigned wa = L.rec + 32u * (unsigned)(i0 * L.m + c);  // may wrap below zero (see above)
+  unsigned wa = L.d + 4u * (unsigned)(i0 * L.m + c);  // may wrap below the plane (see above)
   unsigned wb = wa + pitch, nx = wb + pitch;
   Ops oa = fetch(wa, wb), ob = fetch(wb, nx);
   // both sets have landed before the loop is entered: its waits are then the steady state's (a fetch two steps old)
@@ -3121,7 +3140,7 @@ __device__ inline void bottom_gs_wave(const BLv &L) {
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, O.dS0), __builtin_bit_cast(int, res), 0x111, 0xf,  \
                                            0xf, false));                                                              \
     res = -(dW * O.cf[0] + O.dE * O.cf[1] + dS * O.cf[2] + O.dN * O.cf[3] - O.r) * O.iv; /* MG.pde:84-88 */           \
-    BG_F((im1 < n_) ? W + 32u + 4u * BR_D : dummy, 0u) = res;                                                         \
+    BG_F((im1 < n_) ? W + 4u : dummy, 0u) = res;                                                                      \
     asm volatile("" ::: "memory"); /* the fetch below reads what OTHER lanes have just stored */                      \
     const unsigned ny = nx + pitch;                                                                                   \
     O = fetch(nx, ny);                                                                                                \
