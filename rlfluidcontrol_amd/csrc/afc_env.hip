@@ -525,8 +525,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
         D.mw_H = H;
         D.dbg_copy = cfg->reserved[0];
       }
-      D.sp_i0 = 1 << 30;
-      D.sp_i1 = -1;
+      D.sp_i0 = D.sp_j0 = 1 << 30;
+      D.sp_i1 = D.sp_j1 = -1;
       for (int i = 1; i < L.n - 1; ++i)
         for (int j = 1; j < L.m - 1; ++j) {
           const size_t k = (size_t)i * L.m + j;
@@ -537,9 +537,14 @@ int afc_create(const afc_config *cfg, afc_env **out) {
               L.inv[k] != D.invtab[3 * rc + cc]) {
             if (i < D.sp_i0) D.sp_i0 = i;
             if (i > D.sp_i1) D.sp_i1 = i;
+            if (j < D.sp_j0) D.sp_j0 = j;
+            if (j > D.sp_j1) D.sp_j1 = j;
           }
         }
     }
+    if (getenv("AFC_PRINT_ALLOC"))
+      fprintf(stderr, "afc_create: level %d (%d x %d): special rows [%d, %d], columns [%d, %d]\n", l, L.n - 2, L.m - 2,
+              P.lev[l].sp_i0, P.lev[l].sp_i1, P.lev[l].sp_j0, P.lev[l].sp_j1);
     const int cnt = L.n * L.m;
     lx.insert(lx.end(), L.lx.begin(), L.lx.end());
     ly.insert(ly.end(), L.ly.begin(), L.ly.end());

@@ -45,6 +45,7 @@ struct LevelDesc {
   int zero_bnd;
   float invtab[9];
   int sp_i0, sp_i1;
+  int sp_j0, sp_j1;  // ... and columns [sp_j0, sp_j1] (all rows taken together)
   int dbg_copy;      // StepParams.dbg, reachable from an Lv (diagnostic switches)
   int mw_H;          // strip height of the multi-wave smoother on this level (rows per sweep per strip, <= 63)
 };

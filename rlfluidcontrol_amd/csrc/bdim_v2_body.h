@@ -911,7 +911,7 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   const LevelDesc &D = *L.desc;
   float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
   const bool know = FAST && !ZB && du != nullptr;  // no zeroed boundary faces: inv = invtab[0] everywhere
-  if (FAST) {  // row-dependent part of the analytic inverse diagonal
+  {  // row-dependent part of the analytic inverse diagonal (FAST = false: for the steps outside the special columns)
     if (know) {
       iv0 = du->iv0;
     } else {
@@ -962,18 +962,31 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
     iv_ = load4u(L.inv + kk_);                  \
     ln4_ = L.ly[kk_ + 4];                       \
   }
-  if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
+  // FAST = false (a strip with special rows): only the steps at which some lane stands on one of the level's special
+  // COLUMNS [sp_j0, sp_j1] take the coefficient loads -- the lanes of a step cover columns tau - 26 .. tau + 1, an 8-step
+  // iteration tau0 - 26 .. tau0 + 8 -- and everything before and after runs the FAST code (same bits: outside the special
+  // cells the arrays hold exactly the analytic values, which is what lets whole strips take that path).  Every step of
+  // such a strip through the loads cost 140 ns against 45: the loads are issued one chunk (~150 ns) ahead and come from
+  // L2.  The window's first chunk is fetched here, at the head of the march.
+  int g_lo = 0, g_end = 0;
+  if (!FAST) {
+    const int sj0 = uni(D.sp_j0), sj1 = uni(D.sp_j1);
+    g_lo = (sj0 - 1) & ~7;
+    g_lo = g_lo < 0 ? 0 : (g_lo > steps8 ? steps8 : g_lo);  // (a level without special cells: an empty window at the end)
+    g_end = ((sj1 + 26) & ~7) + 8;
+    GS_CHUNK(g_lo, a_lw, a_le, a_ls, a_iv, a_ln4)
+  }
   float res = 0.f;
   // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
   // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
   // fetched (what they need was stored kLag steps before its use, i.e. by the store just issued).  O = offset of the
   // chunk from the iteration's base addresses; STEADY: no activity mask, interior inverse diagonal
-#define GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
+#define GS3_STEPS(GEN, STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
   _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                                                                   \
     f2u out;                                                                                                           \
     _Pragma("unroll") for (int e = h; e < h + 2; ++e) {                                                                \
       float lw, le, ls, ln, iv;                                                                                        \
-      if (FAST) {                                                                                                      \
+      if (!(GEN)) {                                                                                                    \
         /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:       */ \
         /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                     */ \
         lw = le = ls = ln = cu;                                                                                        \
@@ -990,8 +1003,8 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
         iv = c_iv.v[e];                                                                                                \
       }                                                                                                                \
       /* (k, c-1) holds sweep k at (i-1, j) one step earlier: DPP row_shr:1; c == 0 keeps cW = the row above, in the ring */ \
-      const float t = gs_core<FAST, FAST && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);            \
-      const float v = (FAST && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                             \
+      const float t = gs_core<!(GEN), !(GEN) && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);        \
+      const float v = (!(GEN) && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                           \
       res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                             \
       if (e == h) out.x = res; else out.y = res;                                                                       \
     }                                                                                                                  \
@@ -1001,18 +1014,18 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
     nR[h] = r2.x, nR[h + 1] = r2.y, nW[h] = w2.x, nW[h + 1] = w2.y;                                                    \
     nN[h] = n2.x, nN[h + 1] = n2.y, nE[h] = e2.x, nE[h + 1] = e2.y;                                                    \
   }
-#define GS3_CHUNK2(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, \
-                   n_ln4)                                                                                              \
+#define GS3_CHUNK2(GEN, STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, \
+                   n_iv, n_ln4)                                                                                        \
   {                                                                                                                    \
-    if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
-    GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
+    if (GEN) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                         \
+    GS3_STEPS(GEN, STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                       \
   }
-#define GS3_ITER(STEADY)                                                                                               \
+#define GS3_ITER(GEN, STEADY)                                                                                          \
   {                                                                                                                    \
-    GS3_CHUNK2(STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, \
-               b_ln4)                                                                                                  \
-    GS3_CHUNK2(STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls,   \
-               a_iv, a_ln4)                                                                                            \
+    GS3_CHUNK2(GEN, STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls,  \
+               b_iv, b_ln4)                                                                                            \
+    GS3_CHUNK2(GEN, STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le,    \
+               a_ls, a_iv, a_ln4)                                                                                      \
     /* opaque to the optimiser: the addresses are NOT re-derived from tau0 (one VALU add per access otherwise) */     \
     asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
                  "v_add_u32 %4, 32, %4"                                                                                \
@@ -1022,14 +1035,34 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
   // (lanes without a row -- H < 16 -- run the steady stretch on the zero row: they stay at zero, their stores go to the dummy row)
   const bool all_rows = (I0 - 3 >= 1) && (I0 + H - 1 <= n_);
-  const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
+  const int s_end = (all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
   int tau0 = 0;
-  for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
-  if (FAST)
-    for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
-  for (; tau0 < steps8; tau0 += 8) GS3_ITER(false)
-  if (tau0 < steps)
-    GS3_CHUNK2(false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
+  // straight-line loops, one basic block per 8 steps each (a single loop that picks its body per iteration keeps every
+  // body's operands live everywhere: +100 B of scratch per lane, reloads inside the march, +9.6 % per launch)
+#define GS3_FAST_RANGE(T_END)                                                  \
+  for (; tau0 < (T_END) && tau0 < 32; tau0 += 8) GS3_ITER(false, false)        \
+  for (; tau0 < (T_END) && tau0 < s_end; tau0 += 8) GS3_ITER(false, true)      \
+  for (; tau0 < (T_END); tau0 += 8) GS3_ITER(false, false)
+  if (FAST) {
+    GS3_FAST_RANGE(steps8)
+    if (tau0 < steps)
+      GS3_CHUNK2(false, false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv,
+                 b_ln4)
+  } else {
+    const int w0 = g_lo < steps8 ? g_lo : steps8, w1 = g_end < steps8 ? g_end : steps8;
+    GS3_FAST_RANGE(w0)
+    for (; tau0 < w1; tau0 += 8) GS3_ITER(true, false)
+    GS3_FAST_RANGE(steps8)
+    if (tau0 < steps) {
+      if (tau0 >= g_lo && tau0 < g_end)
+        GS3_CHUNK2(true, false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv,
+                   b_ln4)
+      else
+        GS3_CHUNK2(false, false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv,
+                   b_ln4)
+    }
+  }
+#undef GS3_FAST_RANGE
 #undef GS3_ITER
 #undef LD2
 #undef ST2
@@ -1685,7 +1718,11 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
     }
 #else
     if (tid < 64) {
+#ifdef AFC_FORCE_SPECIAL  // development: every strip marches with the coefficient loads (same bits; prices the non-FAST path)
+      const bool special = true;
+#else
       const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
+#endif
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
         gs_march3<false, true, H>(F, rr, dr, zrow, dummy, I0);

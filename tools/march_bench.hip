@@ -70,6 +70,8 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 9; ++i) D.invtab[i] = -1.f;
   D.sp_i0 = 1 << 30;
   D.sp_i1 = -1;
+  D.sp_j0 = 1;  // generic = 1: every step takes the coefficient loads (special columns = all)
+  D.sp_j1 = m - 2;
   const size_t lds_bytes = (gs_lds_floats(m) + 64) * sizeof(float);
   hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   float *out;
