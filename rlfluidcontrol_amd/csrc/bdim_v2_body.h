@@ -921,8 +921,8 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
       iv2 = D.invtab[3 * rc + 2];
     }
   }
-  const float cu = know ? du->cu : uni(D.cu);
-  const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
+  const float cu = du ? du->cu : uni(D.cu);
+  const bool zb = ZB && (du ? du->zb : uni(D.zero_bnd)) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
   // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
   // iteration and possibly one more at the end
   const int steps = (m_ + (H - 1) + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
@@ -1725,9 +1725,9 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
 #endif
       __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
       if (special)
-        gs_march3<false, true, H>(F, rr, dr, zrow, dummy, I0);
+        gs_march3<false, true, H>(F, rr, dr, zrow, dummy, I0, &du);
       else if (du.zb)
-        gs_march3<true, true, H>(F, rr, dr, zrow, dummy, I0);
+        gs_march3<true, true, H>(F, rr, dr, zrow, dummy, I0, &du);
       else
         gs_march3<true, false, H>(F, rr, dr, zrow, dummy, I0, &du);
       __builtin_amdgcn_s_setprio(0);
