@@ -1718,7 +1718,7 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
     }
 #else
     if (tid < 64) {
-#ifdef AFC_FORCE_SPECIAL  // development: every strip marches with the coefficient loads (same bits; prices the non-FAST path)
+#ifdef AFC_FORCE_SPECIAL  // development: every strip marches as a strip with special rows (same bits; prices that path)
       const bool special = true;
 #else
       const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
