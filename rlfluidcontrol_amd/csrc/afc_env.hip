@@ -563,6 +563,14 @@ int afc_create(const afc_config *cfg, afc_env **out) {
                    (size_t)afc::prod::bottom_lds_floats(P.lev, P.nlev) * sizeof(float) <= env->lds_bytes) ? lb : 0;
   }
 
+  for (int l = 0, off = 0; l < P.nlev; ++l) {  // what bottom_level() needs per level
+    P.lev[l].bot_off = 0;
+    P.lev[l].bot_rcp = (65536u + (unsigned)P.lev[l].m - 1u) / (unsigned)P.lev[l].m;
+    if (P.bottom_lb && l >= P.bottom_lb) {
+      P.lev[l].bot_off = off;
+      off += 32 * afc::prod::bottom_cells4(P.lev[l]);
+    }
+  }
   std::vector<float> brec;  // mg_bottom's table: per bottom level the planes CF {lw, le, ls, ln} | IR {inv, r = 0} | X = 0 | D = 0
   if (P.bottom_lb)
     for (int l = P.bottom_lb; l < P.nlev; ++l) {

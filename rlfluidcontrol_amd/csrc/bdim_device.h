@@ -46,6 +46,8 @@ struct LevelDesc {
   float invtab[9];
   int sp_i0, sp_i1;
   int sp_j0, sp_j1;  // ... and columns [sp_j0, sp_j1] (all rows taken together)
+  int bot_off;       // mg_bottom: byte offset of this level's planes from the first bottom level's (levels >= bottom_lb)
+  unsigned bot_rcp;  // mg_bottom: ceil(2^16 / m), the multiplier of its index -> (row, column) split
   int dbg_copy;      // StepParams.dbg, reachable from an Lv (diagnostic switches)
   int mw_H;          // strip height of the multi-wave smoother on this level (rows per sweep per strip, <= 63)
 };

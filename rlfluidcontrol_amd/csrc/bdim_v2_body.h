@@ -3115,16 +3115,17 @@ __device__ __forceinline__ unsigned b_addr(const BLv &L, unsigned k) {
 #define B_REC4(L, k) (*(lds_f4 *)(uintptr_t)((L).rec + 16u * (unsigned)(k)))
 #define B_F(L, k, f) (*(lds_f *)(uintptr_t)(b_addr<f>((L), (unsigned)(k))))
 __device__ __forceinline__ BLv bottom_level(const StepParams &P, int LB, int l, unsigned base) {
-  unsigned off = 0;
-  for (int q = LB; q < l; ++q) off += 32u * (unsigned)((uni(P.lev[q].n) * uni(P.lev[q].m) + 3) & ~3);
+  // offset and multiplier come ready-made from the host (LevelDesc::bot_off / bot_rcp): summing the levels above and
+  // dividing here was a chain of dependent scalar loads plus an integer division in front of every pass
+  (void)LB;
   BLv L;
   L.n = uni(P.lev[l].n);
   L.m = uni(P.lev[l].m);
   L.n_ = L.n - 2;
   L.m_ = L.m - 2;
   L.cnt = L.n * L.m;
-  L.rcp = (65536u + (unsigned)L.m - 1u) / (unsigned)L.m;
-  L.rec = base + off;
+  L.rcp = (unsigned)uni((int)P.lev[l].bot_rcp);
+  L.rec = base + (unsigned)uni(P.lev[l].bot_off);
   const unsigned c4 = (unsigned)((L.cnt + 3) & ~3);
   L.ir = L.rec + 16u * c4;
   L.x = L.rec + 24u * c4;
