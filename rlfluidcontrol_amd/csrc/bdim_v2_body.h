@@ -506,7 +506,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   const int wave = uni((int)(threadIdx.x >> 6));
   const int ncol = (m_ > 64 * C) ? 2 : 1, nrow = 4 / ncol;
   const int tcol = (ncol == 2) ? (wave & 1) : 0, trow = (ncol == 2) ? (wave >> 1) : wave;
-  const int W = m_ / ncol, lanes_on = W / C;
+  const int W = (ncol == 2) ? (m_ >> 1) : m_, lanes_on = W / C;  // (no runtime division at a phase entry: every wave waits for it)
   // first interior column of the tile; column at ring index 0: always jlo - 2, so that the lane's first cell sits at
   // ring index 2 + C*lane -- for C = 2 every pair of columns (j0 + 2k, j0 + 2k + 1) is one aligned 8-byte LDS read (as
   // dword pairs at odd indices the reads of a wave hit every bank twice).  A left-hand tile's index 0 is "column -1":
@@ -514,7 +514,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   // staged and never used.
   const int jlo = 1 + tcol * W, c0 = jlo - 2;
   const int LQ = (W + 7) >> 2;                            // 16-byte pieces of a staged row (W + 4 columns)
-  const int RPW = (n_ + nrow - 1) / nrow;
+  const int RPW = (ncol == 2) ? ((n_ + 1) >> 1) : ((n_ + 3) >> 2);  // ceil(n_ / nrow), nrow = 4 / ncol
   const int i_first = 1 + trow * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
   const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((2 * NS + 4) * PRB)));  // x ring
   const float nu = uni(P.nu), dt = uni(P.dt);
@@ -1633,12 +1633,14 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
-  const int rstep = kThreads / m, cstep = kThreads - rstep * m;  // flat (row, col) stepping by kThreads
-  const int r0 = tid / m, c0 = tid - r0 * m;
-  double rr_part = 0, xs_part = 0;
-  float linf = 0.f;
   const int CPR = m_ >> 2;
   const bool chunked = ((m_ & 3) == 0);
+  // (integer divisions cost ~30 dependent instructions each, here in front of a barrier every wave waits at: the flat
+  // stepping is only formed for the levels that use it, the chunk split by a shift where the chunk count is a power of two)
+  const int rstep = chunked ? 0 : kThreads / m, cstep = kThreads - rstep * m;  // flat (row, col) stepping by kThreads
+  const int r0 = chunked ? 0 : tid / m, c0 = tid - r0 * m;
+  double rr_part = 0, xs_part = 0;
+  float linf = 0.f;
   const DescU du = desc_u(D);
   UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
   U.NR = NR;
@@ -1646,7 +1648,10 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
   // a thread keeps its 4-column chunk and walks down the rows of its group: no integer division in the strip loops
-  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
+  const bool cpr_p2 = chunked && (CPR & (CPR - 1)) == 0;
+  const int cpr_sh = cpr_p2 ? __builtin_ctz((unsigned)CPR) : 0;
+  const int ngrp = chunked ? (cpr_p2 ? (kThreads >> cpr_sh) : kThreads / CPR) : 1;
+  const int rg = chunked ? (cpr_p2 ? (tid >> cpr_sh) : tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
   const bool grp_on = chunked && (rg < ngrp);
   __syncthreads();
   // Only the zero row has to hold zeros: ring interiors and the ghost columns of d are written by the fills before
@@ -3486,8 +3491,13 @@ __device__ AFC_TAIL_ATTR void project_tail_v2(const bool HEUN, const StepParams 
   const float *pcx = uni(G(P.cx)), *pcy = uni(G(P.cy));
   // a thread walks down one 4-column chunk through its group's rows, so the row above (p west of
   // the x-faces) is the chunk it read one iteration earlier and p crosses HBM once
-  const int ngrp = kThreads / CPR, rg = threadIdx.x / CPR, c4 = threadIdx.x - rg * CPR;
-  const int rpg = (n_ + ngrp - 1) / ngrp;
+  // (chunk counts that are powers of two -- every grid but 384x192 -- split by shifts: three integer divisions less at the
+  // head of the phase)
+  const bool cpr_p2 = (CPR & (CPR - 1)) == 0 && CPR <= kThreads;
+  const int cpr_sh = cpr_p2 ? __builtin_ctz((unsigned)CPR) : 0;
+  const int ngrp = cpr_p2 ? (kThreads >> cpr_sh) : kThreads / CPR;
+  const int rg = cpr_p2 ? ((int)threadIdx.x >> cpr_sh) : (int)threadIdx.x / CPR, c4 = threadIdx.x - rg * CPR;
+  const int rpg = cpr_p2 ? ((n_ + ngrp - 1) >> (8 - cpr_sh)) : (n_ + ngrp - 1) / ngrp;
   const int g_beg = 1 + rg * rpg, g_end = (rg >= ngrp) ? 0 : ((g_beg + rpg - 1 > n_) ? n_ : g_beg + rpg - 1);
   F4 pprev;
   for (int g = g_beg; g <= g_end; ++g) {
@@ -3568,7 +3578,7 @@ __device__ AFC_TAIL_ATTR void project_tail_v2(const bool HEUN, const StepParams 
     setbc_vel(P, vx, vy, lds);
   if (HEUN) {  // whole rows touched by setBC's row part or by its mean correction: 0, 1, n-2, n-1
     for (int q = threadIdx.x; q < 4 * m; q += kThreads) {
-      const int rsel = q / m, j = q - rsel * m;
+      const int rsel = (q >= m) + (q >= 2 * m) + (q >= 3 * m), j = q - rsel * m;  // q / m for q < 4 m
       const int k = ((rsel < 2) ? rsel : (n - 4 + rsel)) * m + j;
       ax[k] = (vx[k] + ox[k]) * 0.5f;
       ay[k] = (vy[k] + oy[k]) * 0.5f;
