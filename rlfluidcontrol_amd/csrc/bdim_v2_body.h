@@ -208,6 +208,8 @@ __device__ __forceinline__ float lane_prev_keep(float own, float v) {  // lane-1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, v), 0x138,
                                                                 0xF, 0xF, false));
 }
+// (callers pass ONE comparison -- a range test as a single unsigned compare: `a && b` reaches the ballot as a 0/1 VGPR and
+// a second compare, four vector instructions instead of one)
 __device__ __forceinline__ lmask lanes_if(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 // (lane in up ? okL : okH) ? a : b -- the mask logic on the scalar unit, one vector select
 __device__ __forceinline__ float sel_upwind_ok(lmask up, lmask okL, lmask okH, float a, float b) {
@@ -357,8 +359,8 @@ __device__ inline void advdif_v2(const StepParams &P, const float *__restrict__ 
         for (int e = 0; e < C; ++e) {
           const int j = j0 + e;
           if (j > m - 2) break;
-          const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
-          const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
+          const lmask mC = lanes_if((unsigned)(j - 2) <= (unsigned)(m - 4));  // column part of the fallback test, as lane masks
+          const lmask mCN = lanes_if((unsigned)(j - 1) <= (unsigned)(m - 4));
           // both components together (x: btype 1, VectorField.pde:183-188; y: btype 2, :189-194)
 #define XY(gi, gj) f2{TX(gi, gj), TY(gi, gj)}
           const f2 cc = XY(i, j), ce = XY(i + 1, j), cw = XY(i - 1, j), cn = XY(i, j + 1), cs = XY(i, j - 1);
@@ -612,8 +614,8 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
 #pragma unroll
       for (int e = 0; e < C; ++e) {
         const int j = j0 + e;
-        const lmask mC = lanes_if((j >= 2) && (j <= m - 2));  // column part of the fallback test, as lane masks
-        const lmask mCN = lanes_if((j + 1 >= 2) && (j + 1 <= m - 2));
+        const lmask mC = lanes_if((unsigned)(j - 2) <= (unsigned)(m - 4));  // column part of the fallback test, as lane masks
+        const lmask mCN = lanes_if((unsigned)(j - 1) <= (unsigned)(m - 4));
         const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
         ccv[e] = cc;
         if (t == 0) {  // the run's first row: its west face (afterwards = the previous row's east face)
@@ -641,8 +643,8 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
         difv[e] = ce + cn - 4.f * cc + cw + cs;  // VectorField.pde:198-200
       }
       if (tcol) {  // right-hand tile: lane 0's south face = the north face of column j0-1, evaluated here (e = -1 above)
-        const lmask mC = lanes_if((j0 - 1 >= 2) && (j0 - 1 <= m - 2));
-        const lmask mCN = lanes_if((j0 >= 2) && (j0 <= m - 2));
+        const lmask mC = lanes_if((unsigned)(j0 - 3) <= (unsigned)(m - 4));
+        const lmask mCN = lanes_if((unsigned)(j0 - 2) <= (unsigned)(m - 4));
         const f2 cc = XY(r2, -1), cn = XY(r2, 0), cs = XY(r2, -2);
         const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{Y_r1[0], cn.y});
         fSw = vn * quick_face2(cs, cc, cn, XY(r2, 1), vn, rok ? mC : 0, rok ? mCN : 0);
