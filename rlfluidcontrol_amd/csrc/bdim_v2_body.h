@@ -501,6 +501,10 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   // it evaluates that face itself, from the two halo columns, with the expression the left tile's last lane uses for
   // its north face.
   constexpr int PR = 64 * C + 4, NS = kAdvNS;    // floats per ring row (16-byte rows); ring rows per field
+  // steady-state wait counts as immediates instead of formed per row (below): measured per kernel instantiation on the same
+  // memory, -0.8 % / -0.5 % per launch in the kernels of the two-tile grids (512x256, 384x192) and +0.2 % in the one-tile
+  // kernel of 256x128 -- each gets the form that is faster for it
+  constexpr bool KST = (TAG == 3 || TAG == 4);
   const int ST = fold ? 4 : 2;  // store instructions per row iteration
   constexpr unsigned PRB = PR * 4u;              // bytes per ring row
   constexpr int YO = NS * PR;                    // floats from a row of the x ring to the same row of the y ring
@@ -558,16 +562,29 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
       {  // how many of the wave's youngest vector-memory operations may still be in flight once row i+2 has landed.
         // Per iteration j, in order: nb base copies (row j+1, if j < i_last), 2 src copies (row j+5, if staged), ST
         // stores (row j); the first iteration issues its src copies last (row i-2 is still read by its west faces).
-        int K;
-        if (t >= 3) {  // the copies of row i+2 were issued in iteration i-3: followed by its stores unless that was the first
-          K = (t > 3) ? ST : 0;
-          for (int jj = i - 2; jj <= i; ++jj) K += ((jj < i_last) ? nb : 0) + ((jj + 5 <= r_hi) ? 2 : 0) + ((jj < i) ? ST : 0);
-        } else {  // ... or by the prologue: rows first-2 .. first+4, then base row first; whole iterations follow
-          // (>= 8 rows per wave, so every base / src copy of the first three iterations exists)
-          K = 2 * (2 - t) + nb + nb + (t > 0 ? 2 : 0);  // rest of the prologue, this iteration's copies
-          K += t * (nb + 2 + ST);                       // earlier iterations
+        if (KST && t > 3 && i + 5 <= r_hi) {
+          // steady state (all but the first four and the last three rows of a run): the count is a constant of the call,
+          // 3 ST + 3 nb + 6 -- formed per row it was ~40 scalar instructions plus wait_vm_le's chain of up to twelve
+          // compare-and-branch pairs
+          if (nb) {
+            if (ST == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          } else {
+            if (ST == 4) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          }
+        } else {
+          int K;
+          if (t >= 3) {  // the copies of row i+2 were issued in iteration i-3: followed by its stores unless that was the first
+            K = (t > 3) ? ST : 0;
+            for (int jj = i - 2; jj <= i; ++jj) K += ((jj < i_last) ? nb : 0) + ((jj + 5 <= r_hi) ? 2 : 0) + ((jj < i) ? ST : 0);
+          } else {  // ... or by the prologue: rows first-2 .. first+4, then base row first; whole iterations follow
+            // (>= 8 rows per wave, so every base / src copy of the first three iterations exists)
+            K = 2 * (2 - t) + nb + nb + (t > 0 ? 2 : 0);  // rest of the prologue, this iteration's copies
+            K += t * (nb + 2 + ST);                       // earlier iterations
+          }
+          wait_vm_le(K);
         }
-        wait_vm_le(K);
       }
       const int j0 = jlo + C * (int)lane_fresh();
       const unsigned lo = ring + 4u * (unsigned)(j0 - c0);
@@ -656,7 +673,11 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
       if (nb) {
         // base row i: copied in iteration i-1 (in front of that iteration's src copies and stores, and of this
         // iteration's copies) or by the prologue
-        wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + ST : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
+        if (KST && t > 0 && i + 5 <= r_hi) {  // steady state: 2 + ST + nb + 2 with nb = 2
+          if (ST == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else
+          wait_vm_le((t > 0 ? ((i + 4 <= r_hi) ? 2 : 0) + ST : 0) + ((i < i_last) ? nb : 0) + ((t > 0 && i + 5 <= r_hi) ? 2 : 0));
         const lds_f *bb = (const lds_f *)(uintptr_t)(lo + (unsigned)(2 * NS + 2 * (i & 1)) * PRB);
         if constexpr (C == 2) {
           const f2 ab = LDP(bb, 0), bb2 = LDP(bb + PR, 0);
