@@ -641,7 +641,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       // batches therefore take the best of a few candidate allocations by a streaming probe (a copy of one half of
       // the buffer onto the other, ~0.5 ms each) and give the others back.  AFC_PLACEMENT_TRIALS=1 switches it off.
       const char *pt = getenv("AFC_PLACEMENT_TRIALS");
-      int trials = pt ? atoi(pt) : 24;  // at most; the search stops early once a fast candidate stands out (below)
+      int trials = pt ? atoi(pt) : 32;  // at most; the search stops early once a fast candidate stands out (below)
       if (slab) trials = 0;
       if (!slab && (total * sizeof(float) < ((size_t)256 << 20) || trials < 1)) trials = 1;
       if (trials > 32) trials = 32;
@@ -675,15 +675,17 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           (void)hipMemsetAsync(q, 0, total * sizeof(float), nullptr);
           if (t == 0) (void)probe(q, 8);  // the first readings of a process come from a device that is still waking up
           rate.push_back(probe(q, 4));
-          // enough: at least six candidates seen and the best stands 3.5 % above their MEDIAN (the two kinds of placement
+          // enough: at least SIXTEEN candidates seen and the best stands 3.5 % above their MEDIAN (the two kinds of placement
           // are 4-5 % apart in this probe; the median is of the slow kind, four in five are) -- or the candidates held
-          // take more than a third of the device's free memory
+          // take more than a third of the device's free memory.  (Six was too few: the slow kind alone spreads over 3 %
+          // in this probe, and four of twenty-one development runs stopped early on the best of the slow ones; a
+          // candidate costs ~3 ms.)
           std::vector<float> srt(rate);
           std::sort(srt.begin(), srt.end());
           const float med = srt[srt.size() / 2], hi = srt.back();
           size_t fr = 0, tot = 0;
           const bool tight = (hipMemGetInfo(&fr, &tot) == hipSuccess) && fr < 2 * cand.size() * total * sizeof(float);
-          if ((cand.size() >= 6 && hi >= 1.035f * med) || tight) break;
+          if ((cand.size() >= 16 && hi >= 1.035f * med) || tight) break;
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
