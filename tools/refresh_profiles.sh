@@ -59,7 +59,7 @@ rm -rf $O/phase_counters
 # (two processes: instances of one process compete for the fast placements) ----
 L=rlfluidcontrol_amd/libafc_env.so
 (echo "AFC_PLACEMENT_TRIALS=1 (first allocation taken), six instances of one process:"; python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 2>&1 | grep "ms per launch";
- echo "default (best of up to 16 candidate allocations by the streaming probe), three instances of one process:"; AFC_PRINT_ALLOC=1 python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L $L $L 2>&1 | grep "ms per launch\|candidate") > $O/${TAG}_placement.txt
+ echo "default (best of 16 to 32 candidate allocations by the streaming probe), three instances of one process:"; AFC_PRINT_ALLOC=1 python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L $L $L 2>&1 | grep "ms per launch\|candidate") > $O/${TAG}_placement.txt
 (cd tools; for kp in 36 42; do for nw in 1 2 4; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DAFC_ONLY_MODE=0 -DNW=$nw -DAFC_KPAD_FORCE=$kp march_bench.hip -o /tmp/mb 2>/dev/null && echo "pitch pad $kp, marching waves per workgroup $nw" && /tmp/mb 0 | grep -v "workgroups=   1"; done; done) > $O/${TAG}_march_bench.txt 2>&1
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do python bench.py --no-cpu-baseline --steps 8 --repeats 2 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['copy_ceiling_measured_GBs'])"; done > $O/${TAG}_placement_reliability.txt
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt
