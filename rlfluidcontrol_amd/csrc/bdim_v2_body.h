@@ -3485,8 +3485,18 @@ __device__ inline void setbc_rows(const StepParams &P, float *ux, float *uy, flo
   }
   lds_barrier();
   if (threadIdx.x == 0) {  // Field.pde:302-318 order (one wave adding the row through v_readlane: 0.25 % SLOWER on the same memory)
+    // eight values per LDS round trip, then eight adds in the same order: as `s += rowbuf[j]` the loop was one LDS read,
+    // a full wait and a branch per element -- ~7 us per call with the other three waves at the barrier
     float s = 0;
-    for (int j = 1; j < m - 1; ++j) s += rowbuf[j];
+    int j = 1;
+    for (; j + 8 <= m - 1; j += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = rowbuf[j + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; j < m - 1; ++j) s += rowbuf[j];
     s /= (float)(m - 2);
     s_mean2 = s;
   }
