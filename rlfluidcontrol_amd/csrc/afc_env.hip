@@ -420,7 +420,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     if (P.impl != 0 && (one_tile || two_tiles) && a3 <= fl && rows_per_wave >= 8) P.adv_ns = afc::prod::kAdvNS;
   }
 
-  P.up2 = (P.impl != 0 && (size_t)afc::prod::gs2_lds_floats(sf.m) * sizeof(float) <= env->lds_bytes) ? 1 : 0;
+  P.up2_unused = 0;
   P.head_v3 = (P.impl != 0 && sf.m == 130 && ((sf.n - 2) & 7) == 0 &&
                (size_t)afc::prod::kHeadLdsFloats * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   P.head_v4 = (P.impl != 0 && afc::prod::head4_shape_ok(sf.n, sf.m) &&

@@ -110,7 +110,7 @@ struct StepParams {
   int adv_ns;          // ring depth (rows) of advdif_v3's per-wave row pipelines; 0 = use advdif_v2
   int head_v3;         // 1: the barrier-free head of the pressure solve (grids of 128 interior columns)
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
-  int up2;             // 1: up-legs with two strips per round and two marching waves (mg_up_smooth2)
+  int up2_unused;      // (was: the two-strip up-leg experiment, removed in round 5; keeps the layout of the block)
   int bottom_lb;       // first multigrid level of the LDS-resident bottom of the V-cycle (mg_bottom); 0 = none
   int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows

@@ -883,7 +883,7 @@ __device__ __host__ constexpr int up_strip_h(int cpl) { return cpl <= 2 ? 16 : (
 // ring rows for strips of H rows: the march has rows I0-4 .. I0+H in flight and the exit reads one row further up
 __device__ __host__ constexpr int up_ring_rows(int H) { return H == 16 ? 24 : H + 6; }
 __device__ __host__ __forceinline__ int gs_lds_floats(int m, int H = 16) {
-  return AFC_KPAD + (2 * up_ring_rows(H) + 2) * ring_pitch(m) + 3 * AFC_KPAD + 8;
+  return AFC_KPAD + (2 * up_ring_rows(H) + 2) * ring_pitch(m) + 3 * AFC_KPAD + 8 + 96 /* kPipeWords */;
 }
 
 // analytic coefficients of an interior cell (LevelDesc) -- used on rows without special cells
@@ -921,9 +921,39 @@ constexpr int kLag = 4;
 // cell: its march then starts without a read of the descriptor.  (Fetching the whole invtab once per level call for the
 // other levels as well measured +0.6 %: eleven more live scalars across the strip loop cost more than the L1 hits at the
 // head of each strip.)
-template <bool FAST, bool ZB = true, int H = 16>
+// Hand-over words of the pipelined up-leg (mg_up_pipe): the marching wave publishes the steps it has completed (one
+// word per lane, so that the store needs no lane mask; readers look at lane 0's), the helper waves publish per column
+// group that a strip's rows have been filled (ff) / have left (xf).  A word stored after data by the same wave is a valid
+// flag: the LDS operations of a wave execute in order.
+struct PipeSync {
+  unsigned mp;       // LDS byte address of THIS lane's progress word
+  const lds_i *ff;   // fill flags, one per column group: >= s once the rows of strip s are in the rings
+  int sbase, s, Q;   // sbase = s << 10 (progress is published as sbase + steps), Q = column groups per row
+};
+// the marching wave waits until the fill flags lo .. hi-1 have reached `need` (lane q looks at flag q)
+__device__ __forceinline__ void pipe_wait_fill(const lds_i *ff, int lo, int hi, int need) {
+  const int l = threadIdx.x & 63;
+  const bool mine = (l >= lo) && (l < hi);
+  for (;;) {
+    const int v = *(volatile const lds_i *)(ff + (l & 15));
+    if (__builtin_amdgcn_ballot_w64(mine && v < need) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");  // nothing that reads the rings moves in front of the wait
+}
+// a helper wave waits until a (wave-uniform) word has reached `need`
+__device__ __forceinline__ void pipe_wait_word(const lds_i *w, int need) {
+  while (uni(*(volatile const lds_i *)w) < need) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pipe_post_word(lds_i *w, int v) {
+  asm volatile("" ::: "memory");  // after everything this wave has read / written in the rings
+  if ((threadIdx.x & 63) == 0) *(volatile lds_i *)w = v;
+}
+constexpr int kPipeHeadGroups = 5;  // column groups (of 16 columns) the first 64 steps of a march can touch
+template <bool FAST, bool ZB = true, int H = 16, bool PIPE = false>
 __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *dr, float *zrow, float *dummy, int I0,
-                                          const DescU *du = nullptr) {
+                                          const DescU *du = nullptr, const PipeSync *ps = nullptr) {
   constexpr int NR = up_ring_rows(H);  // (= kRing for H = 16)
   const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = ring_pitch(m);
   const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
@@ -999,6 +1029,12 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
     g_end = ((sj1 + 26) & ~7) + 8;
     GS_CHUNK(g_lo, a_lw, a_le, a_ls, a_iv, a_ln4)
   }
+  int pv = 0;
+  unsigned q_mp = 0;
+  if (PIPE) {
+    pv = ps->sbase;
+    q_mp = ps->mp;
+  }
   float res = 0.f;
   // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
   // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
@@ -1053,6 +1089,10 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
     asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
                  "v_add_u32 %4, 32, %4"                                                                                \
                  : "+v"(q_rv), "+v"(q_cW), "+v"(q_cN), "+v"(q_dE), "+v"(q_wd));                                        \
+    if (PIPE) { /* steps < tau0 + 8 are stored: tell the helper waves (after the stores: LDS executes in order) */   \
+      pv += 8;                                                                                                         \
+      *(volatile lds_i *)(uintptr_t)q_mp = pv;                                                                         \
+    }                                                                                                                  \
   }
   // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
   // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
@@ -1067,6 +1107,11 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
   for (; tau0 < (T_END) && tau0 < s_end; tau0 += 8) GS3_ITER(false, true)      \
   for (; tau0 < (T_END); tau0 += 8) GS3_ITER(false, false)
   if (FAST) {
+    if (PIPE && ps->Q > kPipeHeadGroups) {  // the columns past the head groups: their fill may still be on its way
+      const int t64 = steps8 < 64 ? steps8 : 64;
+      GS3_FAST_RANGE(t64)
+      pipe_wait_fill(ps->ff, kPipeHeadGroups, ps->Q, ps->s);
+    }
     GS3_FAST_RANGE(steps8)
     if (tau0 < steps)
       GS3_CHUNK2(false, false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv,
@@ -1094,193 +1139,6 @@ __device__ __forceinline__ void gs_march3(const Lv &L, const float *rr, float *d
 #undef GS_CHUNK
 }
 
-// The march for TWO STRIPS IN FLIGHT (mg_up_smooth2): the d ring holds kRing2 rows, r (after the prolongation
-// increment) is not in LDS at all -- every lane streams its row of it from global memory (rg: the level's `d` scratch
-// array, written by the fill; 16 bytes per lane and 4-step chunk, fetched two chunks ahead into the operand set that has
-// just been used up) -- and two waves march consecutive strips: SYNC 1 = the wave of the upper strip publishes the steps
-// it has completed in an LDS word (after its stores: the LDS operations of a wave execute in order), SYNC 2 = the wave
-// of the lower strip follows at kFollow steps: its first row needs the upper strip's last row of the same sweep (15
-// steps behind that strip's first row) and its operand fetches run up to 8 steps ahead of their use.
-constexpr int kRing2 = 40;
-constexpr int kFollow = 32;
-template <bool FAST, bool ZB, int SYNC>
-__device__ __forceinline__ void gs_march4(const Lv &L, const float *rg, float *dr, float *zrow, float *dummy, int I0,
-                                          volatile lds_i *prog, int pbase) {
-  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2, PW = ring_pitch(m);
-  const int lane = threadIdx.x & 63, k = lane >> 4, c = lane & 15;
-  const int i = I0 - k + c;
-  const bool row_ok = (i >= 1) && (i <= n_);
-  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);  // clamped for addressing only
-  const int slot = (ic % kRing2) * PW, slotE = ((ic + 1) % kRing2) * PW;
-  const LevelDesc &D = *L.desc;
-  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
-  if (FAST) {  // row-dependent part of the analytic inverse diagonal
-    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
-    iv0 = D.invtab[3 * rc + 0];
-    iv1 = D.invtab[3 * rc + 1];
-    iv2 = D.invtab[3 * rc + 2];
-  }
-  const float cu = uni(D.cu);
-  const bool zb = ZB && uni(D.zero_bnd) != 0;  // ZB = false: the caller knows the level has no zeroed boundary faces
-  // the last lane (sweep 3, row 15) reaches column m_ at step m_ + 15 + 3*kLag - 1: whole 4-step chunks, two per loop
-  // iteration and possibly one more at the end
-  const int steps = (m_ + 15 + 3 * kLag + 3) & ~3, steps8 = steps & ~7;
-  const unsigned m_eff = row_ok ? (unsigned)m_ : 0u;
-  // Running LDS pointers: at step tau this lane is at column j = tau + jo.  Lanes before the first / past the last
-  // column of their row read a pad and store zeros into it (kPad >= 34 covers the furthest one), lanes whose row lies
-  // outside the grid read the zero row and write to the dummy row.
-  const int jo = 1 - c - kLag * k;
-  unsigned o_rv = 4u * (unsigned)((row_ok ? ic : 1) * m + jo);  // byte offset of this lane's r stream in rg (row 1 for idle lanes)
-  const bool rowW_ok = (i - 1 >= 1) && (i - 1 <= n_);
-  const float *p_cW = (rowW_ok ? dr + ((i - 1) % kRing2) * PW : zrow) + jo;  // d[i-1][j]: only lanes c == 0 use it
-  const float *p_cN = (row_ok ? dr + slot : zrow) + 1 + jo;                 // d[i][j+1] of the previous sweep
-  const float *p_dE = ((row_ok && i + 1 <= n_) ? dr + slotE : zrow) + jo;   // d[i+1][j] of the previous sweep
-  float *w_d = (row_ok ? dr + slot : dummy) + jo;
-  // The five streams of a lane as LDS byte addresses that advance by one opaque add per loop iteration (8 steps): every
-  // access below is `base + immediate`, two consecutive steps per instruction (ds_read2_b32 / ds_write2_b32).
-  unsigned q_cW = lds_addr(p_cW), q_cN = lds_addr(p_cN), q_dE = lds_addr(p_dE), q_wd = lds_addr(w_d);
-#define LD2(q, o) (*(const lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)))
-#define ST2(q, o, v) (*(lds_f2 *)(uintptr_t)((q) + 4u * (unsigned)(o)) = (v))
-  float aR[4], aW[4], aN[4], aE[4], bR[4], bW[4], bN[4], bE[4];
-  int seen = 0;
-  if (SYNC == 2) {  // the very first operand fetch already reads what the upper strip must have finished
-    seen = *prog;
-    for (int spin_ = 0; seen < pbase + kFollow && spin_ < (1 << 18); ++spin_) {
-      __builtin_amdgcn_s_sleep(1);
-      seen = *prog;
-    }
-    asm volatile("" ::: "memory");
-  }
-#pragma unroll
-  for (int h = 0; h < 4; h += 2) {
-    const f2u w2 = LD2(q_cW, h), n2 = LD2(q_cN, h), e2 = LD2(q_dE, h);
-    aW[h] = w2.x, aW[h + 1] = w2.y;
-    aN[h] = n2.x, aN[h + 1] = n2.y, aE[h] = e2.x, aE[h + 1] = e2.y;
-  }
-  {
-    const F4 ta = ld4b(rg, o_rv), tb = ld4b(rg, o_rv + 16u);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) aR[e] = ta.v[e], bR[e] = tb.v[e];
-  }
-  F4 a_lw, a_le, a_ls, a_iv, b_lw, b_le, b_ls, b_iv;
-  float a_ln4 = 0.f, b_ln4 = 0.f;
-  const int cbase = ic * m + jo;  // + tau = flat index of this lane's cell at step tau
-#define GS_CHUNK(TAU, lw_, le_, ls_, iv_, ln4_) \
-  {                                             \
-    int kk_ = cbase + (TAU);                    \
-    kk_ = kk_ < 0 ? 0 : kk_;                    \
-    lw_ = load4u(L.lx + kk_);                   \
-    le_ = load4u(L.lx + kk_ + m);               \
-    ls_ = load4u(L.ly + kk_);                   \
-    iv_ = load4u(L.inv + kk_);                  \
-    ln4_ = L.ly[kk_ + 4];                       \
-  }
-  if (!FAST) GS_CHUNK(0, a_lw, a_le, a_ls, a_iv, a_ln4)
-  float res = 0.f;
-  // one 4-step chunk on operand set (cR,cW,cN,cE / c_*), fetching set (nR,nW,nN,nE / n_*) for the next one, two steps
-  // per LDS instruction: after steps e, e+1 have been stored, the operands of the same two steps of the NEXT chunk are
-  // fetched (what they need was stored kLag steps before its use, i.e. by the store just issued).  O = offset of the
-  // chunk from the iteration's base addresses; STEADY: no activity mask, interior inverse diagonal
-#define GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                         \
-  _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                                                                   \
-    f2u out;                                                                                                           \
-    _Pragma("unroll") for (int e = h; e < h + 2; ++e) {                                                                \
-      float lw, le, ls, ln, iv;                                                                                        \
-      if (FAST) {                                                                                                      \
-        /* every out-of-domain neighbour reads as d = 0, so a boundary face may keep the uniform coefficient:       */ \
-        /* cu*0 == 0*ghost.  Only inv knows about the boundary (coarse levels).                                     */ \
-        lw = le = ls = ln = cu;                                                                                        \
-        iv = iv0;                                                                                                      \
-        if (zb && !(STEADY)) {                                                                                         \
-          const int j = (T0) + jo + e;                                                                                 \
-          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                               \
-        }                                                                                                              \
-      } else {                                                                                                         \
-        lw = c_lw.v[e];                                                                                                \
-        le = c_le.v[e];                                                                                                \
-        ls = c_ls.v[e];                                                                                                \
-        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                                    \
-        iv = c_iv.v[e];                                                                                                \
-      }                                                                                                                \
-      /* (k, c-1) holds sweep k at (i-1, j) one step earlier: DPP row_shr:1; c == 0 keeps cW = the row above, in the ring */ \
-      const float t = gs_core<FAST, FAST && (STEADY)>(res, cW[e], cE[e], cN[e], cR[e], lw, le, ls, ln, iv);            \
-      const float v = (FAST && (STEADY)) ? t : -t * iv; /* MG.pde:84-88 */                                             \
-      res = ((STEADY) || (unsigned)((T0) + jo + e - 1) < m_eff) ? v : 0.f;                                             \
-      if (e == h) out.x = res; else out.y = res;                                                                       \
-    }                                                                                                                  \
-    ST2(q_wd, (O) + h, out);                                                                                           \
-    const f2u w2 = LD2(q_cW, (O) + 4 + h);                                                                             \
-    const f2u n2 = LD2(q_cN, (O) + 4 + h), e2 = LD2(q_dE, (O) + 4 + h);                                                \
-    nW[h] = w2.x, nW[h + 1] = w2.y;                                                                                    \
-    nN[h] = n2.x, nN[h + 1] = n2.y, nE[h] = e2.x, nE[h + 1] = e2.y;                                                    \
-  }                                                                                                                    \
-  { /* r of the chunk after the next one, into the set just used up */                                                \
-    const F4 t_ = ld4b(rg, o_rv + 4u * (unsigned)((O) + 8));                                                           \
-    cR[0] = t_.v[0], cR[1] = t_.v[1], cR[2] = t_.v[2], cR[3] = t_.v[3];                                                \
-  }
-#define GS3_CHUNK2(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4, n_lw, n_le, n_ls, n_iv, \
-                   n_ln4)                                                                                              \
-  {                                                                                                                    \
-    if (!FAST) GS_CHUNK((T0) + 4, n_lw, n_le, n_ls, n_iv, n_ln4)                                                       \
-    GS3_STEPS(STEADY, T0, O, cR, cW, cN, cE, nR, nW, nN, nE, c_lw, c_le, c_ls, c_iv, c_ln4)                            \
-  }
-#define GS3_ITER(STEADY)                                                                                               \
-  {                                                                                                                    \
-    if (SYNC == 2) { /* the upper strip must be kFollow steps ahead of everything this iteration touches */           \
-      const int need_ = pbase + tau0 + kFollow;                                                                        \
-      for (int spin_ = 0; seen < need_ && spin_ < (1 << 18); ++spin_) { /* bounded: never a hang */                     \
-        __builtin_amdgcn_s_sleep(1);                                                                                   \
-        seen = *prog;                                                                                                  \
-      }                                                                                                                \
-      asm volatile("" ::: "memory");                                                                                   \
-    }                                                                                                                  \
-    GS3_CHUNK2(STEADY, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, \
-               b_ln4)                                                                                                  \
-    if (SYNC == 2) seen = *prog; /* read early: consumed at the top of the next iteration */                          \
-    GS3_CHUNK2(STEADY, tau0 + 4, 4, bR, bW, bN, bE, aR, aW, aN, aE, b_lw, b_le, b_ls, b_iv, b_ln4, a_lw, a_le, a_ls,   \
-               a_iv, a_ln4)                                                                                            \
-    /* opaque to the optimiser: the addresses are NOT re-derived from tau0 (one VALU add per access otherwise) */     \
-    asm volatile("v_add_u32 %0, 32, %0\n\tv_add_u32 %1, 32, %1\n\tv_add_u32 %2, 32, %2\n\tv_add_u32 %3, 32, %3\n\t"  \
-                 "v_add_u32 %4, 32, %4"                                                                                \
-                 : "+v"(o_rv), "+v"(q_cW), "+v"(q_cN), "+v"(q_dE), "+v"(q_wd));                                        \
-    if (SYNC == 1) { /* published after the iteration's stores */                                                     \
-      asm volatile("" ::: "memory");                                                                                   \
-      if (lane == 0) *prog = pbase + tau0 + 8;                                                                         \
-      asm volatile("" ::: "memory");                                                                                   \
-    }                                                                                                                  \
-  }
-  // three loops, each one basic block per 8 steps: ramp-up, the steady stretch (strips whose 19 rows all lie inside
-  // the grid: every lane at an interior column 2..m_-1, no activity mask, interior inverse diagonal), ramp-down
-  const bool all_rows = (I0 - 3 >= 1) && (I0 + 15 <= n_);
-  const int s_end = (FAST && all_rows && m_ >= 9) ? (((m_ - 9) & ~7) + 8) : 0;  // steady: 32 <= tau0 <= m_ - 9
-  int tau0 = 0;
-  for (const int lim = steps8 < 32 ? steps8 : 32; tau0 < lim; tau0 += 8) GS3_ITER(false)
-  if (FAST)
-    for (; tau0 < s_end; tau0 += 8) GS3_ITER(true)
-  for (; tau0 < steps8; tau0 += 8) GS3_ITER(false)
-  if (tau0 < steps) {
-    if (SYNC == 2) {
-      const int need_ = pbase + tau0 + kFollow;
-      for (int spin_ = 0; seen < need_ && spin_ < (1 << 18); ++spin_) {
-        __builtin_amdgcn_s_sleep(1);
-        seen = *prog;
-      }
-      asm volatile("" ::: "memory");
-    }
-    GS3_CHUNK2(false, tau0, 0, aR, aW, aN, aE, bR, bW, bN, bE, a_lw, a_le, a_ls, a_iv, a_ln4, b_lw, b_le, b_ls, b_iv, b_ln4)
-  }
-  if (SYNC == 1) {  // done: the follower needs no further permission
-    asm volatile("" ::: "memory");
-    if (lane == 0) *prog = pbase + (1 << 20);
-  }
-#undef GS3_ITER
-#undef LD2
-#undef ST2
-#undef GS3_CHUNK2
-#undef GS3_STEPS
-#undef GS_CHUNK
-}
-
 // prolongate(coarse.x) at a (possibly ghost) cell of the fine level (MG.pde:139-152 incl. setBC)
 __device__ __forceinline__ float prolong_at(const float *__restrict__ xc, int mc, int i, int j, int n_, int m_) {
   const int ci = i < 1 ? 1 : (i > n_ ? n_ : i), cj = j < 1 ? 1 : (j > m_ ? m_ : j);
@@ -1298,7 +1156,6 @@ struct UpGeom {
   int NR = kRing;        // rows in the LDS rings (24 for the strip march, H + 6 for the multi-wave smoother)
   bool store_r = true;   // false: r -= A d is formed (for the norms) but not written back
   bool update_x = true;  // false: replay that only materialises r
-  float *rglob = nullptr;  // mg_up_smooth2: r after the prolongation increment lives HERE (global), not in an LDS ring
   bool al16 = false;       // ring column 1 sits on a 16-byte boundary: the chunk accesses of fill / exit are 128-bit
 };
 struct FillIn {  // r of the chunk + the coarse x values its prolongation stencil touches
@@ -1308,7 +1165,6 @@ struct FillIn {  // r of the chunk + the coarse x values its prolongation stenci
 struct ExitIn {  // x of the chunk, the coarse x under it, the two x ghosts a boundary chunk mirrors into
   F4 x;
   float a1, a2, gl, gh;
-  F4 r;  // mg_up_smooth2 with need_r: r of the chunk (from UpGeom::rglob)
 };
 
 __device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, int g, int c4) {
@@ -1381,11 +1237,7 @@ __device__ __forceinline__ void fill_apply(const UpGeom &U, const bool HASC, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * iv.v[e];  // MG.pde:80
   }
-  if (U.rglob) {
-    if (g <= n_) store4u(U.rglob + g * m + j, rv);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) U.dr[sl + e] = dv.v[e];
-  } else if (U.al16) {  // one ds_write_b128 per ring instead of four stride-4 dword stores (4-way bank conflicts)
+  if (U.al16) {  // one ds_write_b128 per ring instead of four stride-4 dword stores (4-way bank conflicts)
     f4a r4, d4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r4[e] = rv.v[e], d4[e] = dv.v[e];
@@ -1406,16 +1258,12 @@ __device__ __forceinline__ ExitIn exit_load(const UpGeom &U, const bool HASC, in
   ExitIn in;
   const int kk = g * U.m + 1 + 4 * c4;
   in.a1 = in.a2 = in.gl = in.gh = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) in.r.v[e] = 0.f;
   if (!U.update_x) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) in.x.v[e] = 0.f;
-    if (U.rglob) in.r = load4u(U.rglob + kk);
     return in;
   }
   in.x = load4u(U.F->x + kk);
-  if (U.rglob) in.r = load4u(U.rglob + kk);
   if (HASC) {
     const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;
     float a12[2];
@@ -1482,20 +1330,19 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
     float dwv[4], dev[4], rov[4];
     if (U.al16) {
       const f4a w4 = *(const lds_f4 *)(lds_f *)dwp, e4 = *(const lds_f4 *)(lds_f *)dep;
-      f4a o4 = {0.f, 0.f, 0.f, 0.f};
-      if (!U.rglob) o4 = *(const lds_f4 *)(lds_f *)(rr + sl);
+      const f4a o4 = *(const lds_f4 *)(lds_f *)(rr + sl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dwv[e] = w4[e], dev[e] = e4[e], rov[e] = o4[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dwv[e] = dwp[e], dev[e] = dep[e], rov[e] = U.rglob ? 0.f : rr[sl + e];
+      for (int e = 0; e < 4; ++e) dwv[e] = dwp[e], dev[e] = dep[e], rov[e] = rr[sl + e];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float lnv = (e < 3) ? ls.v[(e + 1) & 3] : ln4;
       const float diag = -(lw.v[e] + le.v[e] + ls.v[e] + lnv);
       const float d = d6[1 + e];
-      const float rold = U.rglob ? in.r.v[e] : rov[e];
+      const float rold = rov[e];
       rn.v[e] = rold - (d * diag + dwv[e] * lw.v[e] + dev[e] * le.v[e] + d6[e] * ls.v[e] + d6[2 + e] * lnv);
       const float pr = rn.v[e] * rn.v[e];
       rr_part += (double)pr;
@@ -1848,101 +1695,127 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
   }
 }
 
-// mg_up_smooth with TWO STRIPS PER ROUND and two marching waves (levels whose rows are chunks of four columns and at
-// least 64 rows high -- 34 columns wide: the r stream of a lane starts up to 26 floats before column 1 of its row, which
-// must not fall in front of the array): a round fills 32 rows, waves 0 and 1 march the strips I0 and I0+16 (gs_march4: the second follows
-// the first at kFollow steps), then 32 rows leave.  Half the barriers, fills and exits of mg_up_smooth per level and
-// two strips of the ordered sweep in flight.  What makes room for the second strip's rows: r (after the prolongation
-// increment) is written to the level's global `d` scratch array by the fill and streamed from there by the marching
-// lanes and by the exit, so LDS holds one ring of kRing2 rows of d only.  Same arithmetic, same order, same bits.
-__device__ __host__ __forceinline__ int gs2_lds_floats(int m) {
-  return AFC_KPAD + (40 /*kRing2*/ + 2) * ring_pitch(m) + 4 * AFC_KPAD + 32;
+// mg_up_smooth as a SOFTWARE PIPELINE over the strips (round 5): wave 0 marches strip after strip without a workgroup
+// barrier in between; waves 1-3 follow it column group by column group (16 columns x the 16 rows of a strip per wave
+// and task) -- the rows whose last sweep the march has finished leave (exit of strip s: d.setBC(), increment, MG.pde:90-97)
+// as soon as the march has passed their columns, and the next strip's rows are filled into the ring slots they free
+// (rows I0+17 .. I0+32 take the slots of rows I0-7 .. I0+8: the ring keeps its 24 rows).  Hand-over through progress words
+// in LDS (PipeSync): the march publishes its step count every 8 steps; a helper task waits for the step at which sweep 3
+// of the strip's last row has passed its columns (16 q + 44), loads having been issued before the wait; the march waits
+// for the fill of the next strip's first five column groups at its head and for the rest at step 64.  Same operands in
+// the same order as mg_up_smooth: same bits (the per-thread partial sums of r.r / sum(x) visit the cells in another
+// order -- they are doubles of float terms, re-rounded to float).
+//   task q (0 .. Q) of strip s:  exit of column group q  |  fill of column group q-1 of strip s+1
+// The fill of group q-1 overwrites ring slots that the exits of groups q-2, q-1 (another wave's tasks, earlier ones: xf
+// flags) and q (this task) read -- an exit reads one column to either side of its chunk.
+// For levels of 16-column groups and 16-row strips (m_ % 16 == 0, n_ % 16 == 0); the caller keeps mg_up_smooth otherwise.
+__device__ __host__ __forceinline__ bool up_pipe_shape_ok(int n, int m) {
+  return ((m - 2) & 15) == 0 && ((n - 2) & 15) == 0 && (m - 2) >= 32 && (m - 2) <= 256 && (n - 2) >= 32;
 }
-__device__ inline void mg_up_smooth2(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
-                                     float *rr_out, float *linf_out, ProfT &pf, float *xsum_out = nullptr,
-                                     const int rmode = 0) {
+constexpr int kPipeWords = 64 + 16 + 16;  // progress (one word per lane of the marching wave), xf, ff
+__device__ AFC_UP_ATTR void mg_up_pipe(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
+                                       float *rr_out, float *linf_out, ProfT &pf, float *xsum_out = nullptr,
+                                       const int rmode = 0) {
   const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
   const int PW = ring_pitch(m);
-  const bool mk = need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n));
-  float *dr = lds + kPad, *zrow = dr + kRing2 * PW + kPad, *dummy = zrow + PW + kPad;
-  // the progress word sits beyond everything a lane past the end of the dummy row can reach (kPad + a chunk)
-  volatile lds_i *prog = (volatile lds_i *)(lds_f *)(dummy + PW + kPad + 16);
+  constexpr int H = 16, NR = kRing;
+  float *rr = lds + kPad + 3 + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2), *dr = rr + NR * PW + kPad,
+        *zrow = dr + NR * PW + kPad, *dummy = zrow + PW + kPad;
+  lds_i *flags = (lds_i *)(lds_f *)(dummy + PW + kPad);  // [64 progress words][16 xf][16 ff]
+  lds_i *xf = flags + 64, *ff = flags + 80;
   const int tid = threadIdx.x;
   const LevelDesc &D = *F.desc;
   const int mc = Cc.m;
+  const int CPR = m_ >> 2, Q = m_ >> 4;
   double rr_part = 0, xs_part = 0;
   float linf = 0.f;
-  const int CPR = m_ >> 2;
   const DescU du = desc_u(D);
-  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, dr /* unused r ring */, dr, du};
-  U.NR = kRing2;
+  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
+  U.NR = NR;
+  U.al16 = true;
   U.store_r = (rmode != 1);
   U.update_x = (rmode != 2);
-  U.rglob = F.d;
-  const int ngrp = kThreads / CPR, rg = tid / CPR, c4 = tid - rg * CPR;
-  const bool grp_on = rg < ngrp;
-  const int wave = uni((int)(threadIdx.x >> 6));
   __syncthreads();
-  for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;  // the only LDS words that must hold zeros
-  if (tid == 0) *prog = 0;
-  lds_barrier();
-  int loaded = 0, round = 0;
-  for (int IA = 1; IA - 3 <= n_; IA += 32, ++round) {
-    const int IB = IA + 16;
-    const bool two = (IB - 3 <= n_);          // the round's second strip exists
-    const bool last = (IA + 32 - 3 > n_);      // no further round
-    // ---- fill rows loaded+1 .. hi: r' = r - A prolongate(x_c) to global, d0 = r' * inv into the ring ----
-    const int hi = (two ? IB : IA) + 16;
-    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
-    if (grp_on)
-      for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
+  for (int q = tid; q < PW + 2 * kPad; q += kThreads) zrow[q - kPad] = 0.f;
+  if (tid < kPipeWords) flags[tid] = 0;
+  {  // prologue: rows 1 .. H+1 by all threads (mg_up_smooth's fill of the first strip)
+    const int cpr_sh = __builtin_ctz((unsigned)CPR);
+    const bool cpr_p2 = (CPR & (CPR - 1)) == 0;
+    const int ngrp = cpr_p2 ? (kThreads >> cpr_sh) : kThreads / CPR;
+    const int rg = cpr_p2 ? (tid >> cpr_sh) : tid / CPR, c4 = tid - rg * CPR;
+    const bool sp_fill = (H + 2 >= du.sp_i0) && (0 <= du.sp_i1);
+    if (rg < ngrp)
+      for (int g = 1 + rg; g <= H + 1; g += ngrp) {
         const FillIn in = fill_load(U, HASC, g, c4);
         fill_apply(U, HASC, g, c4, in, sp_fill);
       }
-    loaded = hi;
-    __syncthreads();  // the marching lanes read r' from global memory
-    if (mk) pf.mark(PF_UP0);
-    const int pbase = round << 21;
-    if (wave < 2 && (wave == 0 || two)) {
-      const int I0 = wave ? IB : IA;
-      const bool special = (I0 + 16 >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
-      __builtin_amdgcn_s_setprio(3);
-      // SYNC: 1 = upper strip with a follower, 2 = follower, 0 = a strip alone
-#define GS4(SY)                                                                     \
-  {                                                                                 \
-    if (special)                                                                    \
-      gs_march4<false, true, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);         \
-    else if (du.zb)                                                                 \
-      gs_march4<true, true, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);          \
-    else                                                                            \
-      gs_march4<true, false, SY>(F, F.d, dr, zrow, dummy, I0, prog, pbase);         \
   }
-      if (wave == 1) GS4(2)
-      else if (two) GS4(1)
-      else GS4(0)
-#undef GS4
-      __builtin_amdgcn_s_setprio(0);
+  lds_barrier();
+  if (tid < 64) {
+    PipeSync ps;
+    ps.mp = lds_addr((const float *)(lds_f *)(flags + tid));
+    ps.ff = ff;
+    ps.Q = Q;
+    __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
+    int s = 0;
+    for (int I0 = 1; I0 - 3 <= n_; I0 += H, ++s) {
+      const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
+      ps.s = s;
+      ps.sbase = s << 10;
+      // rows of this strip filled: all column groups for a strip that takes coefficient loads (no wait inside its
+      // march), the groups the first 64 steps can touch otherwise
+      pipe_wait_fill(ff, 0, (special || Q < kPipeHeadGroups) ? Q : kPipeHeadGroups, s);
+      if (special)
+        gs_march3<false, true, H, true>(F, rr, dr, zrow, dummy, I0, &du, &ps);
+      else if (du.zb)
+        gs_march3<true, true, H, true>(F, rr, dr, zrow, dummy, I0, &du, &ps);
+      else
+        gs_march3<true, false, H, true>(F, rr, dr, zrow, dummy, I0, &du, &ps);
+      asm volatile("" ::: "memory");
+      *(volatile lds_i *)(flags + tid) = (s + 1) << 10;  // strip s marched
     }
-    lds_barrier();
-    if (mk) pf.mark(PF_GS0);
-    // ---- exit: rows whose d (and d of both row neighbours) is final ----
-    const int e0 = (IA - 4 < 1) ? 1 : IA - 4, e1 = last ? n_ : ((two ? IB : IA) + 11);
-    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
-    if (grp_on)
-      for (int g = e0 + rg; g <= e1; g += ngrp) {
-        const ExitIn in = exit_load(U, HASC, g, c4);
-        exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    const int hw = (tid >> 6) - 1, l = tid & 63, rI = l >> 2, cq = l & 3;
+    int s = 0;
+    for (int I0 = 1; I0 - 3 <= n_; I0 += H, ++s) {
+      const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + H - 4 >= n_) ? n_ : I0 + H - 5;
+      const bool last = (I0 + H - 3 > n_);  // no further strip: nothing to fill
+      const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
+      const bool sp_fill = (I0 + 2 * H + 1 >= du.sp_i0) && (I0 + H <= du.sp_i1);
+      const int ge = I0 - 4 + rI, gf = I0 + H + 1 + rI;
+      for (int q = hw; q <= Q; q += 3) {
+        const bool ex_on = (q < Q) && (ge >= e0) && (ge <= e1);
+        const bool fi_on = (q >= 1) && !last && (gf <= n_);  // (rows past the grid are never read from the rings)
+        const int cx = 4 * q + cq, cf = cx - 4;
+        ExitIn ein;
+        FillIn fin;
+        if (ex_on) ein = exit_load(U, HASC, ge, cx);
+        if (fi_on) fin = fill_load(U, HASC, gf, cf);
+        if (q < Q) {
+          pipe_wait_word(flags, (s << 10) + 16 * q + 44);  // sweep 3 of the strip's last row has passed column 16 q + 17
+          if (ex_on) exit_apply(U, HASC, need_r, ge, cx, ein, sp_exit, rr_part, xs_part, linf);
+          pipe_post_word(xf + q, s + 1);
+        }
+        if (q >= 1 && !last) {
+          pipe_wait_word(xf + q - 1, s + 1);
+          if (q >= 2) pipe_wait_word(xf + q - 2, s + 1);
+          if (fi_on) fill_apply(U, HASC, gf, cf, fin, sp_fill);
+          pipe_post_word(ff + q - 1, s + 1);
+        }
       }
-    lds_barrier();  // the next round's fill re-uses ring slots this exit has just read
-    if (mk) pf.mark(PF_INC0);
+    }
   }
-  __syncthreads();
+  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
+  if (need_r || (AFC_DIAG && ((F.desc->dbg_copy >> 20) == n))) pf.mark(PF_GS0);
   if (need_r && rmode != 2) {
-    *rr_out = uni((float)block_sum_d(rr_part, sm));
-    *linf_out = uni(block_max_f(linf, sm));
-    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
+    block_reduce3(rr_part, xs_part, linf, lds);
+    *rr_out = uni((float)rr_part);
+    *linf_out = uni(linf);
+    if (xsum_out) *xsum_out = uni((float)xs_part);
   }
 }
+
 
 // =============================================================================================
 // Multi-wave hyperplane smoother: MG.smooth(4) (MG.pde:79-92) with ALL FOUR WAVES of the workgroup.
@@ -3372,8 +3245,8 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
   // levels LB .. kc run out of LDS (mg_bottom) where the host found room for them; LB > kc: level by level as before
   const int LB = (!AFC_RB && uni(P.bottom_lb) >= 2 && !(AFC_DBG_OF(P) & 128)) ? uni(P.bottom_lb) : kc + 1;
   // coarse down-legs as per-wave row pipelines (down_v3c) where the host found room for their rings; the experiments
-  // that use a level's `d` scratch array themselves (dbg bits 2, 8) and dbg bit 4 keep the blocked form
-  const bool down3 = uni(P.down_v3) != 0 && !(AFC_DBG_OF(P) & (4 | 16 | 256));
+  // that use a level's `d` scratch array themselves (dbg bit 2) and dbg bit 4 keep the blocked form
+  const bool down3 = uni(P.down_v3) != 0 && !(AFC_DBG_OF(P) & (4 | 16));
   int iter = 0;
   float linf = 0.f, xsum = 0.f;
   while (iter < P.mg_max_iters) {
@@ -3431,29 +3304,29 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       // action change -- where ALL second cycles of the bench workload occur, 4.7 % of the envs per agent step): its
       // residual is written back right away, so that the stragglers of a launch are spared the replay of the level
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2) && !hard;
-      // two strips per round / two marching waves where the level is big enough and its rings fit the LDS region
-      // two strips per round / two marching waves (mg_up_smooth2): bit-exact, but measured SLOWER than the single march
-      // (DESIGN.md): kept as an experiment of the diagnostic instantiation only (dbg bit 8 switches it on)
-      const bool two_strips = AFC_DIAG && !AFC_RB && uni(P.up2) && ((F.m - 2) & 3) == 0 && (F.n - 2) >= 64 &&
-                              (AFC_DBG_OF(P) & 256);
-      if (two_strips)
-        mg_up_smooth2(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-      else if (!(AFC_DBG_OF(P) & 4)) {
-        if (H0 != 16 && l == 0)
-          mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-        else
-          mg_up_smooth<16>(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-      }
-      else
+      // the up-leg as a software pipeline (mg_up_pipe: the march back to back, waves 1-3 exiting / filling behind it)
+      // where the level has its shape; dbg bit 8: strip by strip with workgroup barriers (mg_up_smooth) everywhere
+#ifndef AFC_PIPE_MAXLEV
+#define AFC_PIPE_MAXLEV 99  // development: levels above this one keep mg_up_smooth
+#endif
+      const bool pipe = !AFC_RB && up_pipe_shape_ok(F.n, F.m) && (l > 0 || H0 == 16) && l <= AFC_PIPE_MAXLEV &&
+                        !(AFC_DBG_OF(P) & 256);
+      if (AFC_DBG_OF(P) & 4)
         mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else if (pipe)
+        mg_up_pipe(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else if (H0 != 16 && l == 0)
+        mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
+      else
+        mg_up_smooth<16>(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
         float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
-        if (two_strips)
-          mg_up_smooth2(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
-        else if (!(AFC_DBG_OF(P) & 4))
-          mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
-        else
+        if (AFC_DBG_OF(P) & 4)
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        else if (pipe)
+          mg_up_pipe(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
+        else
+          mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
       }
       pf.mark(l == 0 ? PF_RR : (16 + l));
     }
