@@ -388,6 +388,7 @@ def main():
                        [round(1e3 * q[0] / args.steps, 3) for q in passes], "ms_per_step_per_rank": per_rank_ms,
                        "gather_ms_per_step": round(float(np.mean(gather_ms)), 4) if gather_ms else 0.0,
                        "gather_share_of_step": round(float(np.mean(gather_ms)) / (1e3 * elapsed / args.steps), 5) if gather_ms else 0.0},
+            "placement": (g.placement_info() if hasattr(g, "placement_info") else None),
             "agent_steps_per_s": round(total_sim / 16.0 / elapsed, 2),
             "diverged_envs": diverged,
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -213,6 +213,16 @@ int afc_op_setbc_u(afc_env *env, float *ux, float *uy);
  * because the rate depends on where the driver puts them), best pass of `reps` per form and placement; *gb_per_s = (bytes read + bytes written) / time / 1e9. */
 int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s);
 
+/* What afc_create's placement search did for this env (no counterpart in the reference).  Batches above 256 MB take the
+ * best of several candidate allocations of the whole state by a streaming probe: where the driver puts a buffer of that
+ * size decides what it streams at (two kinds of placement, 6-7 % apart in the step kernel; the kind follows the physical
+ * region, not the allocation call or its granularity -- tools/vmm_probe.hip).  The candidates are held at once, NEVER
+ * more than a quarter of the device's free memory at the time of the call and at most 32 (AFC_PLACEMENT_TRIALS=n lowers
+ * that, 1 switches the search off); the losers are freed before afc_create returns.  *trials = candidates probed (0: no
+ * search -- small batch, switched off, or no room), *best_gbs / *median_gbs = probe rates of the kept candidate and of
+ * the median one.  A kept candidate less than 3.5 % above the median means the search ended without a fast placement. */
+int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *median_gbs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,7 +170,9 @@ struct afc_env {
   int io_space = AFC_MEM_HOST;
   int E = 0;
   std::vector<void *> allocs;
-  bool slab_shared = false;  // development: the state slab belongs to another instance (AFC_SLAB_PTR)
+  bool slab_shared = false;  // development (AFC_DEVHOOKS builds): the state slab belongs to another instance and is not freed here
+  int place_trials = 0;      // placement search of afc_create: candidates probed (0: no search), best / median probe rate
+  float place_best = 0.f, place_median = 0.f;
   char *arena = nullptr;  // one allocation for all the small device buffers (tables shared by the envs, scalars, staging)
   size_t arena_size = 0, arena_off = 0;
   float *rs_u = nullptr, *rs_v = nullptr, *rs_p = nullptr;  // reset state (device)
@@ -198,7 +200,14 @@ namespace {
 // Buffers of up to 16 MB come out of ONE arena per env (created on first use): the coefficient tables, the multigrid
 // hierarchy and the record table of mg_bottom -- what every workgroup keeps re-reading out of L2 -- then sit in one
 // contiguous range instead of wherever a dozen separate hipMalloc calls put them.  AFC_ARENA=0: separate allocations.
-constexpr size_t kArenaBytes = (size_t)96 << 20, kArenaMaxItem = (size_t)16 << 20;
+// Sized from the case: ~45 arrays of one grid's size (coefficients, body tables, the multigrid hierarchy, reset state)
+// plus per-env staging; what does not fit falls back to a separate allocation.
+constexpr size_t kArenaMaxBytes = (size_t)96 << 20, kArenaMaxItem = (size_t)16 << 20;
+inline size_t arena_bytes_for(size_t cells, size_t envs) {
+  size_t b = 64 * cells * sizeof(float) + envs * 64 + ((size_t)2 << 20);
+  b = (b + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  return b > kArenaMaxBytes ? kArenaMaxBytes : b;
+}
 template <typename T>
 int dev_alloc(afc_env *env, T **p, size_t count) {
   const size_t bytes = count * sizeof(T);
@@ -207,10 +216,11 @@ int dev_alloc(afc_env *env, T **p, size_t count) {
   if (use_arena && bytes <= kArenaMaxItem) {
     if (!env->arena) {
       void *a = nullptr;
-      HIP_TRY(hipMalloc(&a, kArenaBytes));
+      const size_t ab = arena_bytes_for((size_t)env->sf.n * (size_t)env->sf.m, (size_t)env->E);
+      HIP_TRY(hipMalloc(&a, ab));
       env->allocs.push_back(a);
       env->arena = static_cast<char *>(a);
-      env->arena_size = kArenaBytes;
+      env->arena_size = ab;
       env->arena_off = 0;
     }
     const size_t off = (env->arena_off + 255) & ~(size_t)255;
@@ -612,8 +622,12 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     // + 64 floats per field: the row staging copies of advdif_v3 read up to 3 floats past the end of a row -- and ONE float
     // in front of row 0 (a left-hand tile's ring index 0 is "column -1"): kFront floats of padding precede the first field.
     // Development: AFC_ALLOC_MODE=0 restores separate allocations.
+#if AFC_DEVHOOKS
     const char *am = getenv("AFC_ALLOC_MODE");
     const int mode = am ? atoi(am) : 1;
+#else
+    const int mode = 1;
+#endif
     const size_t fsz = ((E * P.Ns + 64 + 63) / 64) * 64, csz = E * (size_t)P.Cs;
     constexpr size_t kFront = 64;
     if (mode == 0) {
@@ -630,51 +644,73 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       const size_t total = kFront + 11 * fsz + csz + scz;
       // development (tools/ab_inproc.py --share-slab): an instance adopts the slab of another instance of the same shape,
       // so that builds are compared on the SAME memory (placements of the fast kind still differ by +-0.5 %)
+      // (compiled in with -DAFC_DEVHOOKS=1 only -- tools/build_variant.sh; the shipped library takes no pointers from
+      // its environment)
+#if AFC_DEVHOOKS
       const char *sp = getenv("AFC_SLAB_PTR");
       if (sp && *sp) {
         slab = reinterpret_cast<float *>(strtoull(sp, nullptr, 0));
         env->slab_shared = true;
       }
+#endif
       // PLACEMENT.  Where the driver puts a buffer of this size decides what it streams at: the same copy kernel runs
       // 4-5 % apart between 1.7 GB allocations of one process, the step kernel 6-7 % (bimodal, stable to 0.1 % per
       // allocation; translation misses are nil either way: tools/ab_inproc.py, tools/alloc_probe.py).  Large
       // batches therefore take the best of a few candidate allocations by a streaming probe (a copy of one half of
       // the buffer onto the other, ~0.5 ms each) and give the others back.  AFC_PLACEMENT_TRIALS=1 switches it off.
+      // The kind of a placement follows the PHYSICAL region the driver hands out (tools/vmm_probe.hip: plain hipMalloc,
+      // one hipMemCreate handle and ranges mapped from 2 / 64 / 256 MB chunks show the same fast / slow pattern by
+      // position in the sequence of allocations, whatever the granularity) -- nothing user space can ask for, so the
+      // search stays, BOUNDED: candidates are held at once (they must be different memory) but never more than a
+      // quarter of the device's free memory at the time of the call, at most 32; a failed probe ends the search with
+      // what has been measured so far.  afc_placement_info() reports what happened.
       const char *pt = getenv("AFC_PLACEMENT_TRIALS");
       int trials = pt ? atoi(pt) : 32;  // at most; the search stops early once a fast candidate stands out (below)
       if (slab) trials = 0;
       if (!slab && (total * sizeof(float) < ((size_t)256 << 20) || trials < 1)) trials = 1;
       if (trials > 32) trials = 32;
+      if (trials > 1) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+          (void)hipGetLastError();
+          trials = 1;
+        } else {
+          const size_t cap = (fr / 4) / (total * sizeof(float));  // candidates that fit a quarter of the free memory
+          if ((size_t)trials > cap) trials = (int)(cap < 1 ? 1 : cap);
+        }
+      }
+      env->place_trials = 0;
+      env->place_best = env->place_median = 0.f;
       if (!rc && trials > 1) {
         std::vector<float *> cand;
         std::vector<float> rate;
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool probe_ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         const size_t n4 = total / 8;  // 16-byte pieces of one half
         auto probe = [&](void *q, int reps) {
           float best = 1e30f;
-          for (int r = 0; r < reps; ++r) {
-            (void)hipEventRecord(e0, nullptr);
+          for (int r = 0; r < reps && probe_ok; ++r) {
+            probe_ok = hipEventRecord(e0, nullptr) == hipSuccess;
             hipLaunchKernelGGL(k_copy_f4<false>, dim3(2048), dim3(256), 0, nullptr, (const f4v *)q, (f4v *)q + n4, n4);
-            (void)hipEventRecord(e1, nullptr);
-            (void)hipEventSynchronize(e1);
+            probe_ok = probe_ok && hipGetLastError() == hipSuccess && hipEventRecord(e1, nullptr) == hipSuccess &&
+                       hipEventSynchronize(e1) == hipSuccess;
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            if (r > 0 && ms < best) best = ms;
+            probe_ok = probe_ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+            if (probe_ok && r > 0 && ms < best) best = ms;
           }
-          return (float)(2.0 * 16.0 * (double)n4 / (best * 1e-3) / 1e9);
+          return probe_ok ? (float)(2.0 * 16.0 * (double)n4 / (best * 1e-3) / 1e9) : 0.f;
         };
-        for (int t = 0; t < trials; ++t) {
+        for (int t = 0; t < trials && probe_ok; ++t) {
           void *q = nullptr;
           if (hipMalloc(&q, total * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();
             break;
           }
           cand.push_back(static_cast<float *>(q));
-          (void)hipMemsetAsync(q, 0, total * sizeof(float), nullptr);
+          if (hipMemsetAsync(q, 0, total * sizeof(float), nullptr) != hipSuccess) probe_ok = false;
           if (t == 0) (void)probe(q, 8);  // the first readings of a process come from a device that is still waking up
           rate.push_back(probe(q, 4));
+          if (!probe_ok) break;  // (the candidate stays in the list with rate 0: it is a usable allocation)
           // enough: at least SIXTEEN candidates seen and the best stands 3.5 % above their MEDIAN (the two kinds of placement
           // are 4-5 % apart in this probe; the median is of the slow kind, four in five are) -- or the candidates held
           // take more than a third of the device's free memory.  (Six was too few: the slow kind alone spreads over 3 %
@@ -683,12 +719,14 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           std::vector<float> srt(rate);
           std::sort(srt.begin(), srt.end());
           const float med = srt[srt.size() / 2], hi = srt.back();
-          size_t fr = 0, tot = 0;
-          const bool tight = (hipMemGetInfo(&fr, &tot) == hipSuccess) && fr < 2 * cand.size() * total * sizeof(float);
-          if ((cand.size() >= 16 && hi >= 1.035f * med) || tight) break;
+          env->place_best = hi;
+          env->place_median = med;
+          if (cand.size() >= 16 && hi >= 1.035f * med) break;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        env->place_trials = (int)cand.size();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipGetLastError();
         int pick = -1;
         for (size_t t = 0; t < cand.size(); ++t)
           if (pick < 0 || rate[t] > rate[pick]) pick = (int)t;
@@ -709,11 +747,13 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       }
       if (!rc) {
         if (getenv("AFC_PRINT_ALLOC")) fprintf(stderr, "afc_create: state slab %p, %zu bytes\n", (void *)slab, total * sizeof(float));
+#if AFC_DEVHOOKS
         if (getenv("AFC_EXPORT_SLAB")) {  // development: tools/ab_inproc.py --share-slab reads the address back
           char buf[32];
           snprintf(buf, sizeof buf, "%p", (void *)slab);
           setenv("AFC_LAST_SLAB", buf, 1);
         }
+#endif
         P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + 11 * fsz + csz);
         size_t k = 0;
         for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + kFront + (k++) * fsz);
@@ -1388,6 +1428,14 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   HIP_TRY(hipMemcpy(&l, dl, sizeof(float), hipMemcpyDeviceToHost));
   if (iters) *iters = it;
   if (resid_linf) *resid_linf = l;
+  return AFC_OK;
+}
+
+int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *median_gbs) {
+  if (!env) return fail(AFC_EINVAL, "afc_placement_info: null env");
+  if (trials) *trials = env->place_trials;
+  if (best_gbs) *best_gbs = env->place_best;
+  if (median_gbs) *median_gbs = env->place_median;
   return AFC_OK;
 }
 

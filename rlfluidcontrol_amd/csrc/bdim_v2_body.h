@@ -455,6 +455,14 @@ __device__ __forceinline__ void wait_vm_le(int K) {
 // One LDS-DMA copy: lane l moves 16 bytes from sbase + voff (its own byte offset) to LDS byte address lds + 16*l.
 // Written as inline assembly so that the compiler's wait-count pass does not see an LDS write it has to drain before
 // the next LDS read: the waits are placed by hand (wait_vm_le).
+// m0: the block sets it and names it as clobbered, but LLVM ignores clobbers of RESERVED registers (the build log says
+// so once per instantiation), and the compiler does use m0 itself (for the LDS-DMA builtin of mg_bottom's table load).
+// What guarantees that neither overwrites the other's value before its use is
+// tests/test_build_resources.py::test_every_lds_dma_sets_m0_right_in_front_of_itself, which reads the shipped disassembly:
+// every mention of m0 in every kernel is an s_mov into it, every global_load_lds finds one within the eight instructions
+// in front of it with no branch, branch target or other copy in between, and no other implicit reader of m0 exists.
+// (Saving and restoring m0 around each copy instead would cost two scalar instructions per row and field in the
+// issue-bound advection.)
 __device__ __forceinline__ void lds_dma16(const float *sbase, unsigned voff, unsigned ldsaddr) {
   const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)ldsaddr);  // uniform by construction; pins it to an SGPR
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uni(sbase)), "s"(la) : "memory", "m0");
@@ -484,7 +492,10 @@ __device__ __forceinline__ unsigned lane_fresh() {
   return l;
 }
 
-template <int C, int TAG = 0>
+// KSTP: the steady-state wait counts as immediates (see KST below) -- by default what the step kernel of the tag ships;
+// the unit-operator kernels pass it explicitly so that tests/test_gpu_parity.py::test_advdif_bit_exact runs the wait path
+// of the step kernel it stands for
+template <int C, int TAG = 0, bool KSTP = (TAG == 3 || TAG == 4)>
 __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                  const float *__restrict__ bx, const float *__restrict__ by, float *__restrict__ dx,
                                  float *__restrict__ dy, float *lds, const bool fold) {
@@ -504,7 +515,7 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   // steady-state wait counts as immediates instead of formed per row (below): measured per kernel instantiation on the same
   // memory, -0.8 % / -0.5 % per launch in the kernels of the two-tile grids (512x256, 384x192) and +0.2 % in the one-tile
   // kernel of 256x128 -- each gets the form that is faster for it
-  constexpr bool KST = (TAG == 3 || TAG == 4);
+  constexpr bool KST = KSTP;
   const int ST = fold ? 4 : 2;  // store instructions per row iteration
   constexpr unsigned PRB = PR * 4u;              // bytes per ring row
   constexpr int YO = NS * PR;                    // floats from a row of the x ring to the same row of the y ring
@@ -3306,11 +3317,10 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       const bool lazy_r = (l == 0) && !P.exact_sums && (((F.m - 2) & 3) == 0) && !(AFC_DBG_OF(P) & 2) && !hard;
       // the up-leg as a software pipeline (mg_up_pipe: the march back to back, waves 1-3 exiting / filling behind it)
       // where the level has its shape; dbg bit 8: strip by strip with workgroup barriers (mg_up_smooth) everywhere
-#ifndef AFC_PIPE_MAXLEV
-#define AFC_PIPE_MAXLEV 99  // development: levels above this one keep mg_up_smooth
-#endif
-      const bool pipe = !AFC_RB && up_pipe_shape_ok(F.n, F.m) && (l > 0 || H0 == 16) && l <= AFC_PIPE_MAXLEV &&
-                        !(AFC_DBG_OF(P) & 256);
+      // (only in the kernels of the grids up to 128 columns, H0 == 16: in the two wide-grid instantiations the same code
+      // on the coarse levels measured +0.3 % (512x256) and +23.7 % (384x192) per launch -- their register allocation
+      // answers the extra branch with reloads inside the loops; they keep round 4's up-leg unchanged)
+      const bool pipe = !AFC_RB && H0 == 16 && up_pipe_shape_ok(F.n, F.m) && !(AFC_DBG_OF(P) & 256);
       if (AFC_DBG_OF(P) & 4)
         mg_up_smooth_mw(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else if (pipe)

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, in
 #define ADV(c)                                                                                    \
   {                                                                                               \
     if (v3)                                                                                       \
-      afc::AFC_MODE_NS::advdif_v3<(c > 2 ? 2 : c), 10 + c>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn, false); \
+      afc::AFC_MODE_NS::advdif_v3<(c > 2 ? 2 : c), 10 + c, (c == 3 || c == 4)>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn, false); \
     else                                                                                          \
       afc::AFC_MODE_NS::advdif_v2<c, 10 + c>(P, G(P.ux), G(P.uy), bx, by, G(P.fx), G(P.fy), lds_dyn);    \
   }

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
     "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases", "afc_format_float_java", "afc_get_cfl",
     "afc_get_window_complete", "afc_get_mg_histogram", "afc_measure_copy_rate", "afc_op_project",
+    "afc_placement_info",
 ]
 
 
@@ -97,6 +98,11 @@ def load_library():
     try:  # entry points added in round 4: absent from the older builds tools/ab.sh compares against (AFC_ENV_LIB)
         L.afc_op_project.argtypes = [vp, f32p, f32p, f32p, i32p, C.POINTER(C.c_float)]
         L.afc_measure_copy_rate.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
+    except AttributeError:
+        if not os.environ.get("AFC_ENV_LIB"):
+            raise
+    try:  # round 5
+        L.afc_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     except AttributeError:
         if not os.environ.get("AFC_ENV_LIB"):
             raise
@@ -287,6 +293,15 @@ class AFCEnv:
         out = np.zeros(8, np.int64)
         self._ck(self._L.afc_get_mg_histogram(self._h, _np_ptr(out), int(clear)), "afc_get_mg_histogram")
         return out
+
+    def placement_info(self):
+        """what afc_create's placement search did: {"trials", "best_GBs", "median_GBs", "hit"} (include/afc_env.h)"""
+        if not hasattr(self._L, "afc_placement_info"):
+            return None
+        t, b, m = C.c_int32(0), C.c_float(0), C.c_float(0)
+        self._ck(self._L.afc_placement_info(self._h, C.byref(t), C.byref(b), C.byref(m)), "afc_placement_info")
+        return {"trials": int(t.value), "best_GBs": round(float(b.value), 1), "median_GBs": round(float(m.value), 1),
+                "hit": bool(t.value > 1 and b.value >= 1.035 * m.value)}
 
     def diverged(self):
         out = np.empty(self.num_envs, np.uint8)

@@ -185,8 +185,14 @@ class Agent:
     """agent_TD3.py:10-184.  `get_action`, `train_iter`, `record`, `reset_agent`, `reset_episode`
     keep the reference's names and meaning; states/actions may carry any batch size."""
 
-    def __init__(self, state_dim, action_dim, explore_noise="Gaussian", device="cpu", seed=None, num_envs=1, world=1):
+    # Transitions per env and episode of the reference's case (clientCFD.pde: 16-step windows from t = 1 to t = 50 at
+    # dt = 0.0075): what a rank's replay ring has to hold per env to cover one whole episode.
+    STEPS_PER_EPISODE = 410
+
+    def __init__(self, state_dim, action_dim, explore_noise="Gaussian", device="cpu", seed=None, num_envs=1, world=1,
+                 replay_capacity=None, replay_episodes=3):
         self.world = world  # > 1: sharded learner (gradients averaged over the ranks, see _sync_grads)
+        self.num_envs = num_envs
         self.n_grad_allreduce = 0
         self.lr, self.gamma, self.tau = 1e-4, 0.99, 0.005
         self.bs, self.bfs, self.d = 512, 1000000, 2
@@ -206,9 +212,15 @@ class Agent:
         self._build()
         if world > 1:
             self._sync_from_rank0(seed)
-        # sharded learner: the job's replay capacity stays the reference's 1 M transitions (agent_TD3.py:27), a 1/world
-        # share per rank -- every rank stores the transitions of its own envs only
-        self.replay_buffer = ReplayBuffer(state_dim, action_dim, self.bfs // max(world, 1), device=self.device)
+        # Replay capacity PER RANK (a rank stores the transitions of its own envs only, time-major): the reference's
+        # 1 M (agent_TD3.py:27) spans ~2400 single-env episodes; a batched rank writes num_envs transitions per agent
+        # step, so the ring must hold whole episodes of ALL its envs or training never sees the early part of an
+        # episode (1024 envs x 410 steps = 420 k per episode: a 1 M / world share would keep the last ~120 agent steps
+        # only).  max(1 M, replay_episodes x num_envs x STEPS_PER_EPISODE) transitions of 32 bytes each.
+        local_envs = max(1, int(num_envs) // max(int(world), 1))  # (num_envs counts the envs of ALL ranks)
+        self.replay_capacity = int(replay_capacity) if replay_capacity else max(
+            self.bfs, int(replay_episodes) * local_envs * self.STEPS_PER_EPISODE)
+        self.replay_buffer = ReplayBuffer(state_dim, action_dim, self.replay_capacity, device=self.device)
         self.step_count = self.total_step_count = self.episode_count = self.train_count = 0
 
     def _nets(self):
@@ -330,7 +342,7 @@ class Agent:
         self.step_count += 1
 
     def reset_agent(self):
-        self.replay_buffer = ReplayBuffer(self.state_dim, self.action_dim, self.bfs // max(self.world, 1), device=self.device)
+        self.replay_buffer = ReplayBuffer(self.state_dim, self.action_dim, self.replay_capacity, device=self.device)
         self.step_count = self.total_step_count = self.train_count = self.episode_count = 0
         self._build()
         if self.world > 1:

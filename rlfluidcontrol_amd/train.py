@@ -15,9 +15,10 @@ Every rank steps its shard and the one all-gather per agent step of `ShardedVecE
 observation; every rank evaluates the same actor on it (identical weights, identical generator state), the reference's
 only RL collective has the same shape (rank 0 asks the agent and `MPI_Bcast`s the two action values,
 clientNektar/Fourier/src/drive.C:1561).  The LEARNER IS SHARDED: a rank stores the transitions of its own envs only
-(E x 407 per episode) in a FIFO of 1/world of the reference's 1 M transitions -- the job keeps the reference's total
-replay capacity, but a batch is world equal shares drawn from the ranks' own FIFOs instead of one uniform draw over
-one FIFO (a deliberate deviation in sampling, not in capacity) -- and trains on a 1/world share of every batch (the
+(E x 407 per episode) in a FIFO of its own that holds at least three whole episodes of all its envs (max(1 M, 3 x E x
+410) transitions of 32 bytes: the reference's 1 M spans ~2400 single-env episodes, a 1 M / world share would keep only
+the last ~120 agent steps of a 1024-env rank) -- a batch is world equal shares drawn from the ranks' own FIFOs instead
+of one uniform draw over one FIFO (a deliberate deviation in sampling) -- and trains on a 1/world share of every batch (the
 batch size must be a multiple of the world size); the gradients are averaged with one all-reduce per optimiser step
 (~0.8 MB), so the weights stay bit-identical across ranks (tests/test_train_sharded_gloo.py): the ranks start from
 rank 0's weights and generator state (broadcast at construction, seeded or not).

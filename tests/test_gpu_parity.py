@@ -158,7 +158,7 @@ def test_setbc_u(envmod, oracle_mod):
 
 
 @pytest.mark.parametrize("impl", [0, 2])
-@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100), (24, 500)])
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100), (24, 500), (32, 400)])
 def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re, impl):
     """MGsolver on the env's own coefficient hierarchy, random divergence-like rhs"""
     g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re, impl=impl)

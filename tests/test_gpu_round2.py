@@ -189,6 +189,50 @@ def test_cfg4_full_size_1024_envs_512x256(envmod):
     one.close()
 
 
+def test_native_full_size_1024_envs_384x192(envmod):
+    """the reference's own case at the batch size of the headline: 1024 envs on the 384x192 Re 500 grid (clientCFD.pde:5-14;
+    96-column tiles, 12-row strips on the finest level, an odd-width coarsest level), started from the reference-held
+    init.bdim.  All envs get the same inputs: bit-identical to each other and to a single env run alone, no divergence,
+    one V-cycle per solve from a developed state."""
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "init_bdim_res24.npz"))
+    E, res, Re = 1024, 24, 500
+    g = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re)
+    one = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=Re)
+    for h in (g, one):
+        h.set_reset_state(z["u"], z["v"], z["p"])
+        h.reset()
+    acts = [(0.0, 0.0), (2.5, -4.0), (2.5, -4.0), (-1.0, 3.0)]
+    for a in acts:
+        fg = g.update2(np.tile(np.array([a], np.float32), (E, 1)))
+        f1 = one.update2(np.array([a], np.float32))
+        assert np.all(fg == fg[0]) and np.array_equal(fg[0], f1[0])
+    assert g.diverged().sum() == 0
+    for e in (0, 255, 256, 777, 1023):
+        for x, y in zip(g.get_state(e), one.get_state(0)):
+            assert np.array_equal(x, y)
+    it, rs = g.solver_stats()
+    assert it.max() <= 2 and np.all(np.isfinite(rs))
+    g.close()
+    one.close()
+
+
+def test_impl2_rejects_grids_taller_than_256_cells_and_impl0_runs_them(envmod):
+    """AFCCylinder.pde:12-13 sizes the grid from yLengths*resolution without a cap; the optimised kernels are instantiated
+    for up to 256 cells in y (four columns per lane).  A taller grid must be refused LOUDLY by impl 2 (never computed
+    wrongly) and is served by the straightforward kernels (impl 0), which have no such limit."""
+    with pytest.raises(envmod.AfcError) as ei:
+        envmod.AFCEnv(num_envs=1, resolution=40, reynolds=100, impl=2)  # 640 x 320 (2^p x 5: a valid multigrid size)
+    assert "256 cells in y" in str(ei.value)
+    g = envmod.AFCEnv(num_envs=1, resolution=40, reynolds=100, impl=0)
+    assert (g.n, g.m) == (16 * 40 + 2, 8 * 40 + 2)
+    f = g.update2(np.zeros((1, 2), np.float32))
+    assert np.all(np.isfinite(f))
+    u, v, p = g.get_state(0)
+    assert np.all(np.isfinite(u)) and np.all(np.isfinite(p))
+    g.close()
+
+
 def test_cfg5_td3_in_the_loop_at_1024_envs(envmod):
     """BASELINE cfg5's per-GPU workload: 1024 envs x 256x128 with the TD3 learner on the same device -- the
     episode protocol up to the 8th request (149 + 7x16 sim-steps per env), transitions assembled, 8 TD3 iterations."""
