@@ -552,6 +552,19 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           }
         }
     }
+    // perf mode: up-leg as register-resident row pipelines where the level has the shape and the rows that cross a body
+    // (their coefficient rows are staged in LDS) fit the region; AFC_RBW=<mask of levels>, 0: the barrier form everywhere (same bits)
+    P.lev[l].rbw = 0;
+    {
+      const char *ev = getenv("AFC_RBW");
+      // default: the finest level only -- measured per level (1024 envs, 256x128, ms per launch against 33.7 for the barrier
+      // form everywhere): level 0 alone 32.6, level 1 alone 33.9, level 2 alone 35.7, levels 3-6 36.6, all 37.1: on the small
+      // levels a wave's serial walk of n_ + 19 steps (almost all of them boundary / body steps) loses to 256 threads x few barriers
+      const int lmask = ev ? atoi(ev) : 1;  // (bit l: level l)
+      if (cfg->gs_mode == 1 && ((lmask >> l) & 1) && afc::prod::up_rbw_shape_ok(L.n, L.m) &&
+          (size_t)afc::prod::up_rbw_lds_floats(L.m, P.lev[l].sp_i0, P.lev[l].sp_i1) * sizeof(float) <= env->lds_bytes)
+        P.lev[l].rbw = 1;
+    }
     if (getenv("AFC_PRINT_ALLOC"))
       fprintf(stderr, "afc_create: level %d (%d x %d): special rows [%d, %d], columns [%d, %d]\n", l, L.n - 2, L.m - 2,
               P.lev[l].sp_i0, P.lev[l].sp_i1, P.lev[l].sp_j0, P.lev[l].sp_j1);

@@ -50,6 +50,7 @@ struct LevelDesc {
   unsigned bot_rcp;  // mg_bottom: ceil(2^16 / m), the multiplier of its index -> (row, column) split
   int dbg_copy;      // StepParams.dbg, reachable from an Lv (diagnostic switches)
   int mw_H;          // strip height of the multi-wave smoother on this level (rows per sweep per strip, <= 63)
+  int rbw;           // perf mode: 1 = the level's up-leg runs as register-resident row pipelines (mg_up_rbw)
 };
 
 struct SampleDev {

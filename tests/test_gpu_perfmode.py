@@ -195,3 +195,46 @@ def test_perf_mode_solver_is_red_black_multigrid(envmod, res, Re):
     print("perf-mode MG vs numpy red-black: res %d, %d iterations, max|dx| %.3g of max|x| %.3g" % (res, it, float(np.abs(xg - x).max()), scale))
     assert np.array_equal(xg, x), (float(np.abs(xg - x).max()), scale)
     g.close()
+
+
+def test_register_resident_row_pipelines_equal_the_barrier_form_bit_for_bit(envmod, monkeypatch):
+    """mg_up_rbw (round 5: the perf-mode up-leg as temporally blocked row pipelines out of registers, one per wave) runs
+    the same half-sweeps on the same operands as the barrier form (gs_rb_stage): one and two V-cycles of the solver on
+    the 128x64 and 256x128 hierarchies with EVERY level on the new path (AFC_RBW = mask of levels; the default is level
+    0 only) against the barrier form everywhere, and 20 whole steps with the default."""
+    def solve(res, mask, iters):
+        monkeypatch.setenv("AFC_RBW", str(mask))
+        g = envmod.AFCEnv(num_envs=1, resolution=res, reynolds=100, gs_mode=1, mg_max_iters=iters)
+        rng = np.random.default_rng(3)
+        b = np.zeros((g.n, g.m), np.float32)
+        b[1:-1, 1:-1] = 1e-2 * rng.standard_normal((g.n - 2, g.m - 2)).astype(np.float32)
+        b[1:-1, 1:-1] -= b[1:-1, 1:-1].mean()
+        x, it, l = g.op_mg_solve(np.zeros_like(b), b)
+        g.close()
+        return x, it, l
+    for res in (8, 16):
+        for iters in (1, 2):
+            x0, it0, l0 = solve(res, 0, iters)
+            for mask in (1, 2, 4, 127):
+                x1, it1, l1 = solve(res, mask, iters)
+                assert it0 == it1 and np.array_equal(x0, x1), (res, iters, mask)
+
+    def steps(mask):
+        if mask is None:
+            monkeypatch.delenv("AFC_RBW", raising=False)
+        else:
+            monkeypatch.setenv("AFC_RBW", str(mask))
+        g = envmod.AFCEnv(num_envs=3, resolution=16, reynolds=100, gs_mode=1)
+        xi = np.array([[0.0, 0.0], [3.0, -2.0], [-4.0, 1.0]], np.float32)
+        f = [g.update2(xi).copy() for _ in range(20)]
+        st = [g.get_state(e) for e in range(3)]
+        it, _ = g.solver_stats()
+        g.close()
+        return f, st, it
+    f0, s0, i0 = steps(0)
+    f1, s1, i1 = steps(None)
+    assert np.array_equal(i0, i1)
+    for a, b in zip(f0, f1):
+        assert np.array_equal(a, b)  # (r.r / sum(p) partial sums are doubles of float terms: the forces agree to the bit here)
+    for (u0, v0, p0), (u1, v1, p1) in zip(s0, s1):
+        assert np.array_equal(u0, u1) and np.array_equal(v0, v1) and np.array_equal(p0, p1)
