@@ -954,7 +954,10 @@ __device__ __forceinline__ void pipe_wait_fill(const lds_i *ff, int lo, int hi, 
 }
 // a helper wave waits until a (wave-uniform) word has reached `need`
 __device__ __forceinline__ void pipe_wait_word(const lds_i *w, int need) {
-  while (uni(*(volatile const lds_i *)w) < need) __builtin_amdgcn_s_sleep(1);
+#ifndef AFC_PIPE_SLEEP
+#define AFC_PIPE_SLEEP 1
+#endif
+  while (uni(*(volatile const lds_i *)w) < need) __builtin_amdgcn_s_sleep(AFC_PIPE_SLEEP);
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void pipe_post_word(lds_i *w, int v) {
