@@ -32,8 +32,8 @@ DEFAULT_INIT = {(16, 100): os.path.join(GOLDEN, "wake_res16_re100.npz"),
                 (24, 500): os.path.join(GOLDEN, "init_bdim_res24.npz")}
 # BASELINE.json workloads by (res, Re, envs per GPU)
 # HBM traffic per launch measured with rocprofv3 --pmc on exactly these kernel sources (tools/pmc_traffic.py), by workload
-TRAFFIC_FILES = {(16, 100, 1024): "r4_hbm_traffic.json", (32, 400, 1024): "r4_hbm_traffic_cfg4.json",
-                 (24, 500, 1024): "r4_hbm_traffic_native.json"}
+TRAFFIC_FILES = {(16, 100, 1024): "r5_hbm_traffic.json", (32, 400, 1024): "r5_hbm_traffic_cfg4.json",
+                 (24, 500, 1024): "r5_hbm_traffic_native.json"}
 WORKLOADS = {(16, 100, 1024): "BASELINE.json configs[1]",
              (32, 400, 1024): "BASELINE.json configs[3]",
              (24, 500, 1024): "reference-native 384x192 Re500 (init.bdim)"}

@@ -1790,6 +1790,9 @@ __device__ AFC_UP_ATTR void mg_up_pipe(const bool HASC, const Lv &F, const Lv &C
     }
     __builtin_amdgcn_s_setprio(0);
   } else {
+    // (lane -> (row, chunk) with the chunk running fastest: four lanes read 64 contiguous bytes of a row.  With the ROW
+    // running fastest the 128-bit LDS accesses would be free of bank conflicts -- rows are 12 (mod 32) banks apart -- and the
+    // launch is 0.9 % slower: the global accesses of a lane quad then fall into four different rows)
     const int hw = (tid >> 6) - 1, l = tid & 63, rI = l >> 2, cq = l & 3;
     int s = 0;
     for (int I0 = 1; I0 - 3 <= n_; I0 += H, ++s) {

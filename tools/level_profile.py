@@ -32,7 +32,8 @@ def run(nrows):
 
 
 base = run(0)
-print("E=%d: env 0, us per sim-step (both half-steps)" % E)
+print("E=%d: env 0, us per sim-step (both half-steps); a level whose up-leg runs as the software pipeline (mg_up_pipe) has ONE mark:" % E)
+print("its whole up-leg is listed under `march`, fill and exit run beside it")
 print("%-8s %8s %8s %8s %8s" % ("level", "fill", "march", "exit", "whole"))
 print("%-8s %8.1f %8.1f %8.1f %8.1f" % ("L0", base["up0"], base["gs0"], base["inc0"], base["up0"] + base["gs0"] + base["inc0"]))
 for l, n in enumerate([130, 66, 34, 18, 10, 6], start=1):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ on a GPU box (run through gpurun from the repo root):
-#   tools/refresh_profiles.sh <tag>      e.g. r4   -> gpurun_out/profiles_<tag>/
+#   tools/refresh_profiles.sh <tag>      e.g. r5   -> gpurun_out/profiles_<tag>/
 # For each of the three measured grids (BASELINE configs[1] 256x128, configs[3] 512x256, reference-native 384x192): the
 # bench line with cpu_baseline and roofline.traffic (HBM bytes per launch from two PMC passes on the same sources), and the
 # lock-step phase times.  For the headline grid also: rocprofv3 kernel stats, steady launch average, SQ / LDS counters,
 # per-phase counters and traffic, per-level profile, the perf-mode line with its counters, the march micro-benchmark and
 # the memory-placement evidence (tools/ab_inproc.py).
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -61,5 +61,9 @@ L=rlfluidcontrol_amd/libafc_env.so
 (echo "AFC_PLACEMENT_TRIALS=1 (first allocation taken), six instances of one process:"; python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 2>&1 | grep "ms per launch";
  echo "default (best of 16 to 32 candidate allocations by the streaming probe), three instances of one process:"; AFC_PRINT_ALLOC=1 python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L $L $L 2>&1 | grep "ms per launch\|candidate") > $O/${TAG}_placement.txt
 (cd tools; for kp in 36 42; do for nw in 1 2 4; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DAFC_ONLY_MODE=0 -DNW=$nw -DAFC_KPAD_FORCE=$kp march_bench.hip -o /tmp/mb 2>/dev/null && echo "pitch pad $kp, marching waves per workgroup $nw" && /tmp/mb 0 | grep -v "workgroups=   1"; done; done) > $O/${TAG}_march_bench.txt 2>&1
+# ---- round 5: launch time against the number of envs (1 .. 4 workgroups per CU), the up-leg alone, the placement probe ----
+(for E in 1 256 512 768 1024; do python tools/ab_inproc.py --envs $E --blocks 4 --per-block 4 $L 2>&1 | grep "ms per launch" | sed "s/^/E=$E  /"; done) > $O/${TAG}_launch_time_by_envs.txt
+(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -o /tmp/ub tools/upleg_bench.hip 2>/dev/null && for a in "128 0 1 1" "64 1 0 0" "32 1 0 0"; do /tmp/ub $a; done) > $O/${TAG}_upleg_bench.txt 2>&1
+(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value -o /tmp/vp tools/vmm_probe.hip 2>/dev/null && /tmp/vp 1740 10) > $O/${TAG}_vmm_placement_probe.txt 2>&1
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do python bench.py --no-cpu-baseline --steps 8 --repeats 2 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['copy_ceiling_measured_GBs'])"; done > $O/${TAG}_placement_reliability.txt
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt
