@@ -69,10 +69,12 @@ def test_committed_traffic_figure_belongs_to_the_shipped_kernel_sources():
     d = _line()
     tname = bench.TRAFFIC_FILES[(16, 100, 1024)]
     tpath = os.path.join(ROOT, "profiles", tname)
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if d["config"]["kernel_src_sha16"] == tj["kernel_src_sha16"]:
-            assert d["roofline"]["traffic"] == tj["hbm_bytes_per_launch"] and d["config"]["dbg"] == 0
+    tj = json.load(open(tpath))
+    # the committed profiles belong to the committed kernel sources: whoever edits a kernel file re-runs
+    # tools/refresh_profiles.sh before committing, or this fails
+    assert tj["kernel_src_sha16"] == bench.kernel_source_hash(), "profiles/%s was measured on other kernel sources" % tname
+    assert d["config"]["kernel_src_sha16"] == tj["kernel_src_sha16"]
+    assert d["roofline"]["traffic"] == tj["hbm_bytes_per_launch"] and d["config"]["dbg"] == 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'tj.get("kernel_src_sha16") == kernel_source_hash()' in src  # the guard itself
 
