@@ -1834,23 +1834,8 @@ __device__ AFC_UP_ATTR void mg_up_pipe(const bool HASC, const Lv &F, const Lv &C
 }
 
 
-// =============================================================================================
-// Multi-wave hyperplane smoother: MG.smooth(4) (MG.pde:79-92) with ALL FOUR WAVES of the workgroup.
-//
-// Wave k runs sweep k; lane l (1..H) of wave k owns row i = I0 - k - 1 + l of a strip of H rows (the strip of
-// sweep k is shifted up by k rows, so sweep k never needs a row its predecessor has not finished), lane 0 re-plays
-// row I0 - k - 1, which the previous strip finished, so that every real lane finds d[i-1][j] in lane-1.
-// At global step tau the lane is at column j = tau - l - S*k + 1.  The four neighbours of cell (i,j) in sweep k:
-//   d[i-1][j] (sweep k)   computed one step earlier by lane l-1  -> DPP wave_shr:1
-//   d[i][j-1] (sweep k)   computed one step earlier by this lane -> register
-//   d[i+1][j] (sweep k-1) | both were written to the LDS array D by wave k-1 exactly S steps earlier (k == 0: d0 =
-//   d[i][j+1] (sweep k-1) | r*inv left there by the fill) and are overwritten by this very sweep one step LATER
-// which is the order the sequential loops of the reference see, so every cell gets the reference's bits.
-// Steps are grouped in chunks of 4 with ONE LDS barrier per chunk: a chunk reads its operands from LDS one chunk
-// ahead, computes 4 steps in registers and writes its 4 results; S = 8 guarantees that what a chunk prefetches was
-// written at least one barrier earlier (4q+e+4-S <= 4q-1) and that nothing it still needs has been overwritten.
-// D and R (r after the prolongation increment) are rings of NR = H + 6 full-width rows; r is read-only here.
-// ---------------------------------------------------------------------------------------------
+// (the all-waves hyperplane smoother lives in bdim_v2_multiwave.h, diagnostic instantiation only; its LDS footprint is
+// sized by the host in every instantiation)
 constexpr int kMwS = 8;
 constexpr int kMwGuardLo = 96, kMwGuardMid = 160;  // lanes outside their row read (and ignore) whatever lies there
 
@@ -1866,673 +1851,11 @@ __device__ __forceinline__ float lane_next(float v) {  // the value lane+1 holds
 }
 
 
-// (host side of mg_up_rbw, perf mode: which levels it serves -- in every instantiation, the host asks afc::prod)
-__device__ __host__ __forceinline__ bool up_rbw_shape_ok(int n, int m) {
-  const int n_ = n - 2, m_ = m - 2;
-  return (m_ & 1) == 0 && m_ >= 2 && m_ <= 128 && n_ >= 2;
-}
-__device__ __host__ __forceinline__ int up_rbw_lds_floats(int m, int sp_i0, int sp_i1) {
-  const int ns = (sp_i1 >= sp_i0) ? sp_i1 - sp_i0 + 1 : 0;
-  return (3 * ns + 1) * m + 16;
-}
-#if AFC_RB
-// =============================================================================================
-// PERF MODE, round 5: the whole up-leg of a level -- prolongation increment, d = r*inv, the eight colour half-sweeps of
-// four red-black Gauss-Seidel sweeps, d.setBC(), increment (MG.pde:73-97 with the smoother's loops in red-black order)
-// -- as INDEPENDENT ROW PIPELINES, one per wave, temporally blocked, out of REGISTERS: no LDS ring, no workgroup
-// barrier, no flags.  Wave w owns rows a .. b of the level and walks down rows lo = a - 9 .. hi = b + 9.  Lane l holds
-// the two cells (2l+1, 2l+2) of every row of a window of twelve rows (d and r after the prolongation increment: 48
-// registers); the four neighbours of a cell are the same lane's registers of the rows above / below, the lane's other
-// cell, and one value from lane-1 or lane+1 (DPP wave_shr / wave_shl).  In step T the wave
-//   fills row T                (r - A prolongate(coarse.x), d = r*inv: one 8-byte load per lane, the coarse row of the
-//                               lane's column pair -- prolongation is constant over 2x2 cells)
-//   applies half-sweep h to row T-1-h, h = 0 .. 7 (its inputs, the other colour of rows T-2-h .. T-h after half-sweep
-//                               h-1, were produced earlier in this step / in step T-1: the dependency cone of the eight
-//                               half-sweeps is what the nine halo rows on either side are for -- they are recomputed
-//                               by both neighbours, identically, and written by neither)
-//   lets row T-9 leave         (rows T-10 .. T-8 are final: d.setBC(), x += d (+ prolongate), r -= A d for the norms)
-// Which cell of a lane a half-sweep updates depends on the parity of the row: the step function is instantiated for the
-// twelve window slots, so slot indices and parities are compile-time constants and the window stays in registers.
-// Rows that cross a body take their coefficients from a copy of those rows of lx / ly / inv staged in LDS by all waves
-// at the start of the call.  Every cell sees the half-sweeps in the order of the barrier form (gs_rb_stage) with the
-// same operands in the same order: same bits (tests/test_gpu_perfmode.py pins the solver on a numpy red-black multigrid).
-// For levels of an even number of at most 128 columns whose staged rows fit the LDS region (LevelDesc::rbw, set by the
-// host); on the finest level only when the new residual is not written back (rmode 1: a wave reads the old r of its
-// neighbours' rows) -- the barrier form serves the rest.
-constexpr int kRbwP = 12, kRbwHalo = 9;
-struct RbwCtx {  // wave-uniform
-  const float *r, *xc;
-  float *x, *rout;
-  const lds_f *slx, *sly, *sinv;  // the staged rows sp0 .. sp1 (+1 for lx) of the coefficient arrays
-  int n_, m_, m, mc, lo, hi, a, b, sp0, sp1;
-  bool hasc, need_r, store_r, update_x, zb;
-  float cu, iv0;
-};
-struct RbwLane {
-  int jA;
-  bool on, first, last;
-  float ivA0, ivA1, ivA2, ivB0, ivB1, ivB2;  // inverse diagonal of the lane's two cells by row class (levels with zeroed boundary faces)
-  float lsA, lnB, diagA, diagB;              // interior rows, exact form: south face of cell A / north face of cell B, diagonals
-};
-struct RbwWin {
-  float dA[kRbwP], dB[kRbwP], rA[kRbwP], rB[kRbwP];
-  float cm, c0, cp;  // prolongate(coarse.x) of the lane's column pair in rows T-1, T, T+1
-};
-__device__ __forceinline__ float rbw_coarse(const RbwCtx &C, int t, int l) {  // MG.pde:139-152 incl. the setBC mirror
-  const int tc = t < 1 ? 1 : (t > C.n_ ? C.n_ : t);
-  return C.xc[((tc - 1) / 2 + 1) * C.mc + l + 1];
-}
-// coefficients of cell (i, jA + B); exact: boundary faces of a zero_bnd level are 0 (fill / exit), else every face = cu
-// (the smoother: an out-of-domain neighbour reads as d = 0, so cu * 0 == 0 * ghost)
-template <bool B>
-__device__ __forceinline__ void rbw_coef(const RbwCtx &C, const RbwLane &Ln, int i, const bool exact, float &lw, float &le,
-                                         float &ls, float &ln, float &iv) {
-  if (i >= C.sp0 && i <= C.sp1) {
-    const int o = (i - C.sp0) * C.m + Ln.jA + (B ? 1 : 0);
-    lw = C.slx[o];
-    le = C.slx[o + C.m];
-    ls = C.sly[o];
-    ln = C.sly[o + 1];
-    iv = C.sinv[o];
-  } else {
-    const bool r1 = (i == 1), rn = (i == C.n_);
-    const bool z = exact && C.zb;
-    lw = (z && r1) ? 0.f : C.cu;
-    le = (z && rn) ? 0.f : C.cu;
-    ls = (z && !B && Ln.first) ? 0.f : C.cu;
-    ln = (z && B && Ln.last) ? 0.f : C.cu;
-    if (C.zb)
-      iv = B ? (r1 ? Ln.ivB1 : (rn ? Ln.ivB2 : Ln.ivB0)) : (r1 ? Ln.ivA1 : (rn ? Ln.ivA2 : Ln.ivA0));
-    else
-      iv = C.iv0;
-  }
-}
-// One step of the walk (see above).  S = T mod kRbwP: window slots and row parities are compile-time constants.
-// FAST: every row the step touches (T-10 .. T) is an interior row of the grid (2 .. n_-1) without special cells -- no
-// row tests, analytic coefficients from the lane's constants.  The general form tests each row (inside the grid?
-// crossing a body? first / last row?) with wave-uniform branches.  Rows of the grid outside the wave's own cone
-// (lo .. hi) are treated like any other: what they hold never reaches a row the wave owns.
-template <int S, bool FAST>
-__device__ __forceinline__ void rbw_step(const RbwCtx &C, const RbwLane &Ln, RbwWin &W, const int T, double &rr_part,
-                                         double &xs_part, float &linf) {
-#define RBW_SL(k) ((((S) - (k)) % kRbwP + kRbwP) % kRbwP)
-  const int l = (Ln.jA - 1) >> 1;
-  {  // ---- fill row T ----
-    const int g = T;
-    float rvA = 0.f, rvB = 0.f, dvA = 0.f, dvB = 0.f;
-    if (FAST || (g >= 1 && g <= C.n_)) {
-      float r2[2];
-      __builtin_memcpy(r2, C.r + g * C.m + Ln.jA, 8);
-      rvA = r2[0], rvB = r2[1];
-      float lwA, leA, lsA, lnA, ivA, lwB, leB, lsB, lnB, ivB, diagA, diagB;
-      if (FAST) {
-        lwA = leA = lnA = lwB = leB = lsB = C.cu;
-        lsA = Ln.lsA, lnB = Ln.lnB, diagA = Ln.diagA, diagB = Ln.diagB;
-        ivA = Ln.ivA0, ivB = Ln.ivB0;
-      } else {
-        rbw_coef<false>(C, Ln, g, true, lwA, leA, lsA, lnA, ivA);
-        rbw_coef<true>(C, Ln, g, true, lwB, leB, lsB, lnB, ivB);
-        diagA = -(lwA + leA + lsA + lnA), diagB = -(lwB + leB + lsB + lnB);
-      }
-      if (C.hasc) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order, as fill_apply)
-        const float c0 = W.c0, cw = W.cm, ce = W.cp;
-        const float cprev = lane_prev_keep(c0, c0);
-        const float cnx = lane_next(c0), cnext = Ln.last ? c0 : cnx;
-        rvA = rvA - (c0 * diagA + cw * lwA + ce * leA + cprev * lsA + c0 * lnA);
-        rvB = rvB - (c0 * diagB + cw * lwB + ce * leB + c0 * lsB + cnext * lnB);
-      }
-      rvA = Ln.on ? rvA : 0.f;
-      rvB = Ln.on ? rvB : 0.f;
-      dvA = rvA * ivA;  // MG.pde:80
-      dvB = rvB * ivB;
-    }
-    if (C.hasc) {
-      W.cm = W.c0;
-      W.c0 = W.cp;
-      W.cp = rbw_coarse(C, g + 2, l);
-    }
-    W.rA[RBW_SL(0)] = rvA;
-    W.rB[RBW_SL(0)] = rvB;
-    W.dA[RBW_SL(0)] = dvA;
-    W.dB[RBW_SL(0)] = dvB;
-  }
-  // ---- half-sweep h on row T-1-h ----
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    const int i = T - 1 - h;
-    // the row's parity is that of S - 1 - h (T - S is a multiple of kRbwP, which is even): half-sweep h takes the cells with
-    // (i + j) & 1 == (h & 1), i.e. cell B (even column) of the rows with (i & 1) == (h & 1)
-    const bool cellB = ((((S - 1 - h) % 2) + 2) % 2) == (h & 1);
-    const int si = RBW_SL(1 + h), sw = RBW_SL(2 + h), se = RBW_SL(h);
-    if (FAST || (i >= 1 && i <= C.n_)) {
-      float lw, le, ls, ln, iv;
-      if (cellB) {
-        if (FAST)
-          lw = le = ls = ln = C.cu, iv = Ln.ivB0;
-        else
-          rbw_coef<true>(C, Ln, i, false, lw, le, ls, ln, iv);
-        const float dW = (FAST || i > 1) ? W.dB[sw] : 0.f, dE = (FAST || i < C.n_) ? W.dB[se] : 0.f;
-        const float dS = W.dA[si], dN = lane_next(W.dA[si]);
-        const float t = dW * lw + dE * le + dS * ls + dN * ln - W.rB[si];
-        const float v = -t * iv;  // MG.pde:84-88
-        W.dB[si] = Ln.on ? v : 0.f;
-      } else {
-        if (FAST)
-          lw = le = ls = ln = C.cu, iv = Ln.ivA0;
-        else
-          rbw_coef<false>(C, Ln, i, false, lw, le, ls, ln, iv);
-        const float dW = (FAST || i > 1) ? W.dA[sw] : 0.f, dE = (FAST || i < C.n_) ? W.dA[se] : 0.f;
-        const float dS = lane_prev(W.dB[si]), dN = W.dB[si];
-        const float t = dW * lw + dE * le + dS * ls + dN * ln - W.rA[si];
-        const float v = -t * iv;
-        W.dA[si] = Ln.on ? v : 0.f;
-      }
-    }
-  }
-  {  // ---- row T-9 leaves: d.setBC(); x += d; r -= A d   (MG.pde:90-97, as exit_apply) ----
-    const int g = T - 9;
-    const bool own = (g >= C.a) && (g <= C.b);
-    if (own) {  // (wave-uniform)
-      const int sg = RBW_SL(9), sw = RBW_SL(10), se = RBW_SL(8);
-      const float dA = W.dA[sg], dB = W.dB[sg];
-      const int kk = g * C.m + Ln.jA;
-      float dp = 0.f;
-      if (C.hasc) dp = rbw_coarse(C, g, l);
-      if (C.need_r) {
-        const float dWa = (FAST || g > 1) ? W.dA[sw] : dA, dEa = (FAST || g < C.n_) ? W.dA[se] : dA;  // the ghost rows mirror (setBC)
-        const float dWb = (FAST || g > 1) ? W.dB[sw] : dB, dEb = (FAST || g < C.n_) ? W.dB[se] : dB;
-        const float pv = lane_prev(dB), nx = lane_next(dA);
-        const float dSa = Ln.first ? dA : pv, dNb = Ln.last ? dB : nx;
-        float lwA, leA, lsA, lnA, ivA, lwB, leB, lsB, lnB, ivB, diagA, diagB;
-        if (FAST) {
-          lwA = leA = lnA = lwB = leB = lsB = C.cu;
-          lsA = Ln.lsA, lnB = Ln.lnB, diagA = Ln.diagA, diagB = Ln.diagB;
-        } else {
-          rbw_coef<false>(C, Ln, g, true, lwA, leA, lsA, lnA, ivA);
-          rbw_coef<true>(C, Ln, g, true, lwB, leB, lsB, lnB, ivB);
-          diagA = -(lwA + leA + lsA + lnA), diagB = -(lwB + leB + lsB + lnB);
-        }
-        const float rnA = W.rA[sg] - (dA * diagA + dWa * lwA + dEa * leA + dSa * lsA + dB * lnA);
-        const float rnB = W.rB[sg] - (dB * diagB + dWb * lwB + dEb * leB + dA * lsB + dNb * lnB);
-        if (Ln.on) {
-          const float pa = rnA * rnA, pb = rnB * rnB;
-          rr_part += (double)pa;
-          rr_part += (double)pb;
-          linf = jmax(linf, jabs(rnA));
-          linf = jmax(linf, jabs(rnB));
-          if (C.store_r) {
-            const float o2[2] = {rnA, rnB};
-            __builtin_memcpy(C.rout + kk, o2, 8);
-          }
-        }
-      }
-      if (C.update_x && Ln.on) {
-        float x2[2];
-        __builtin_memcpy(x2, C.x + kk, 8);
-        float xa = x2[0], xb = x2[1];
-        if (C.hasc) xa = xa + dp, xb = xb + dp;
-        xa = xa + dA;
-        xb = xb + dB;
-        if (C.need_r) {
-          xs_part += (double)xa;
-          xs_part += (double)xb;
-        }
-        const float o2[2] = {xa, xb};
-        __builtin_memcpy(C.x + kk, o2, 8);
-        // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
-        if (Ln.first) {
-          float xg = C.x[kk - 1];
-          if (C.hasc) xg = xg + dp;
-          C.x[kk - 1] = xg + dA;
-        }
-        if (Ln.last) {
-          float xg = C.x[kk + 2];
-          if (C.hasc) xg = xg + dp;
-          C.x[kk + 2] = xg + dB;
-        }
-        if (!FAST && (g == 1 || g == C.n_)) {
-          const int kg = ((g == 1) ? 0 : (C.n_ + 1)) * C.m + Ln.jA;
-          float g2[2];
-          __builtin_memcpy(g2, C.x + kg, 8);
-          float ga = g2[0], gb = g2[1];
-          if (C.hasc) ga = ga + dp, gb = gb + dp;
-          const float q2[2] = {ga + dA, gb + dB};
-          __builtin_memcpy(C.x + kg, q2, 8);
-          if (Ln.first) {
-            float xg = C.x[kg - 1];
-            if (C.hasc) xg = xg + dp;
-            C.x[kg - 1] = xg + dA;
-          }
-          if (Ln.last) {
-            float xg = C.x[kg + 2];
-            if (C.hasc) xg = xg + dp;
-            C.x[kg + 2] = xg + dB;
-          }
-        }
-      }
-    }
-  }
-#undef RBW_SL
-}
-__device__ __forceinline__ void mg_up_rbw(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, float *rr_out,
-                                 float *linf_out, float *xsum_out, const int rmode) {
-  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
-  const int tid = threadIdx.x;
-  const LevelDesc &D = *F.desc;
-  const DescU du = desc_u(D);
-  const int ns = (du.sp_i1 >= du.sp_i0) ? du.sp_i1 - du.sp_i0 + 1 : 0;
-  // the rows sp_i0 .. sp_i1 of lx (one more: the east faces of the last row), ly and inv, staged once per call
-  float *slx = lds + (((16u - (lds_addr(lds) & 15u)) & 15u) >> 2), *sly = slx + (ns + 1) * m, *sinv = sly + ns * m;
-  __syncthreads();
-  if (ns > 0) {
-    const int o = du.sp_i0 * m;
-    for (int q = tid; q < (ns + 1) * m; q += kThreads) slx[q] = F.lx[o + q];
-    for (int q = tid; q < ns * m; q += kThreads) {
-      sly[q] = F.ly[o + q];
-      sinv[q] = F.inv[o + q];
-    }
-    if (tid == 0) sinv[ns * m] = 0.f;  // (ly of the cell past the last staged one is read by an idle lane)
-  }
-  __syncthreads();
-  double rr_part = 0, xs_part = 0;
-  float linf = 0.f;
-  const int w = uni((int)(threadIdx.x >> 6));
-  const int nw = (n_ >= 128) ? 4 : ((n_ >= 32) ? 2 : 1);
-  const int RW = (n_ + nw - 1) / nw;
-  const int a = 1 + w * RW, b = (a + RW - 1 < n_) ? a + RW - 1 : n_;
-  if (w < nw && a <= n_) {
-    RbwCtx C;
-    C.r = F.r, C.xc = Cc.x, C.x = F.x, C.rout = F.r;
-    C.slx = (const lds_f *)slx, C.sly = (const lds_f *)sly, C.sinv = (const lds_f *)sinv;
-    C.n_ = n_, C.m_ = m_, C.m = m, C.mc = uni(Cc.m);
-    C.a = a, C.b = b;
-    C.lo = (a - kRbwHalo < 1) ? 1 : a - kRbwHalo;
-    C.hi = (b + kRbwHalo > n_) ? n_ : b + kRbwHalo;
-    C.sp0 = du.sp_i0, C.sp1 = du.sp_i1;
-    C.hasc = HASC, C.need_r = need_r, C.store_r = (rmode != 1), C.update_x = (rmode != 2), C.zb = du.zb != 0;
-    C.cu = du.cu, C.iv0 = du.iv0;
-    RbwLane Ln;
-    const int l0 = tid & 63;
-    const int l = (2 * l0 + 2 <= m_) ? l0 : 0;
-    Ln.on = (2 * l0 + 2 <= m_);
-    Ln.jA = Ln.on ? 2 * l + 1 : 1;  // (idle lanes alias column 1: every address stays inside the arrays, every result is masked)
-    Ln.first = (l0 == 0);
-    Ln.last = (2 * l0 + 2 == m_);
-    Ln.ivA0 = Ln.ivA1 = Ln.ivA2 = Ln.ivB0 = Ln.ivB1 = Ln.ivB2 = du.iv0;
-    if (C.zb) {  // invtab[3 * row class + column class] (class 0 interior, 1 first, 2 last)
-      const int ca = Ln.first ? 1 : 0, cb = Ln.last ? 2 : 0;
-      Ln.ivA0 = D.invtab[ca], Ln.ivA1 = D.invtab[3 + ca], Ln.ivA2 = D.invtab[6 + ca];
-      Ln.ivB0 = D.invtab[cb], Ln.ivB1 = D.invtab[3 + cb], Ln.ivB2 = D.invtab[6 + cb];
-    }
-    // interior rows, exact form (fill / exit): the only zeroed faces are the wall columns' (levels with zeroed boundary faces)
-    Ln.lsA = (C.zb && Ln.first) ? 0.f : C.cu;
-    Ln.lnB = (C.zb && Ln.last) ? 0.f : C.cu;
-    Ln.diagA = -(C.cu + C.cu + Ln.lsA + C.cu);
-    Ln.diagB = -(C.cu + C.cu + C.cu + Ln.lnB);
-    RbwWin W;
-#pragma unroll
-    for (int q = 0; q < kRbwP; ++q) W.dA[q] = W.dB[q] = W.rA[q] = W.rB[q] = 0.f;
-    W.cm = W.c0 = W.cp = 0.f;
-    if (HASC) {
-      W.cm = rbw_coarse(C, C.lo - 1, l);
-      W.c0 = rbw_coarse(C, C.lo, l);
-      W.cp = rbw_coarse(C, C.lo + 1, l);
-    }
-    const int Tend = C.b + 9;  // row b leaves in step b + 9 (rows past hi are filled like any other: harmless)
-    for (int T0 = (C.lo / kRbwP) * kRbwP; T0 <= Tend; T0 += kRbwP) {
-#define RBW_STEP(S_)                                                                                       \
-  {                                                                                                        \
-    const int T_ = T0 + (S_);                                                                              \
-    if (T_ >= C.lo && T_ <= Tend) {                                                                        \
-      if (T_ - 10 >= 2 && T_ <= n_ - 1 && (T_ < C.sp0 || T_ - 10 > C.sp1))                                \
-        rbw_step<S_, true>(C, Ln, W, T_, rr_part, xs_part, linf);                                          \
-      else                                                                                                 \
-        rbw_step<S_, false>(C, Ln, W, T_, rr_part, xs_part, linf);                                         \
-    }                                                                                                      \
-  }
-      RBW_STEP(0) RBW_STEP(1) RBW_STEP(2) RBW_STEP(3) RBW_STEP(4) RBW_STEP(5)
-      RBW_STEP(6) RBW_STEP(7) RBW_STEP(8) RBW_STEP(9) RBW_STEP(10) RBW_STEP(11)
-#undef RBW_STEP
-    }
-  }
-  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
-  if (need_r && rmode != 2) {
-    block_reduce3(rr_part, xs_part, linf, lds);
-    *rr_out = uni((float)rr_part);
-    *linf_out = uni(linf);
-    if (xsum_out) *xsum_out = uni((float)xs_part);
-  }
-}
-#endif  // AFC_RB
+#include "bdim_v2_rbw.h"
 
-// dst = (lane is a re-play lane) ? b : a, as one v_cndmask on a constant lane mask (kept opaque: written as a C
-// select the compiler predicates the whole update on it and pays an exec-mask branch per step)
-__device__ __forceinline__ float sel_mask(float a, float b, unsigned long long mk) {
-  float r;
-  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mk));
-  return r;
-}
-
-// PER = sweeps per wave.  PER 1: wave k = sweep k, up to 62 rows per strip.  PER 2: waves 0 and 1 carry two sweeps
-// each (lanes 0-31 / 32-63), up to 30 rows per strip -- the form for the finest level, whose strips are LDS-bound
-// to ~28 rows: half the instruction streams for the same step count.  Waves wait for each other through progress
-// words in LDS (a wave publishes the number of the chunk it has finished; the next sweep's wave checks it before it
-// prefetches), not through workgroup barriers: LDS operations of one wave execute in order, so a consumer that sees
-// the progress word also sees the data written before it.
-// Not inlined on purpose: every instantiation gets its own register allocation instead of inflating the live ranges
-// of the phases around it.
-template <bool FAST, bool ZB, int PER>
-__device__ __noinline__ void gs_multiwave(const Lv &L, const float *Rg, float *Dg, float *dummyg, int NR, int I0,
-                                          int Lmax, int gbase) {
-  const int wave = threadIdx.x >> 6;
-  if (PER == 2 && wave >= 2) return;
-  const lds_f *R = (const lds_f *)Rg;
-  lds_f *D = (lds_f *)Dg;
-  lds_f *dummy = (lds_f *)dummyg;
-  volatile lds_i *prog = (volatile lds_i *)(dummy + 64);  // [4] progress words
-  const int m = L.m, n_ = L.n - 2, m_ = L.m - 2;
-  const int lane64 = threadIdx.x & 63;
-  const int lane = (PER == 2) ? (lane64 & 31) : lane64;
-  const int k = (PER == 2) ? (2 * wave + (lane64 >> 5)) : wave;
-  const unsigned long long replay = (PER == 2) ? 0x100000001ull : 1ull;
-  const int i = I0 - k - 1 + lane;
-  const bool rowin = (i >= 1) && (i <= n_);
-  const bool is0 = (lane == 0);
-  const bool real = rowin && !is0 && (lane <= Lmax);
-  const unsigned m_on = (real || (rowin && is0)) ? (unsigned)m_ : 0u;  // columns 1..m_on produce a value
-  const unsigned m_wr = real ? (unsigned)m_ : 0u;                     // ... and are stored
-  const int ic = i < 0 ? 0 : (i > n_ ? n_ : i);
-  const int so = (ic % NR) * m;
-  const int se = is0 ? so : ((ic + 1) % NR) * m;  // re-play lanes fetch their own (finished) row through the east stream
-  const int jo = 1 - lane - kMwS * k;
-  const LevelDesc &Dsc = *L.desc;
-  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;
-  if (FAST) {
-    const int rc = (i == 1) ? 1 : ((i == n_) ? 2 : 0);
-    iv0 = Dsc.invtab[3 * rc + 0];
-    iv1 = Dsc.invtab[3 * rc + 1];
-    iv2 = Dsc.invtab[3 * rc + 2];
-  }
-  const float cu = uni(Dsc.cu);
-  const int T = (m_ + Lmax + 3 * kMwS + 7) & ~7;  // two chunks per loop iteration
-  const lds_f *pR = R + so + jo, *pE = D + se + jo, *pN = D + so + jo + 1;
-  lds_f *pW = D + so + jo;
-  lds_f *dmy = dummy + lane64;
-  float aR[4], aE[4], aN[4], bR[4], bE[4], bN[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    aR[e] = pR[e];
-    aE[e] = pE[e];
-    aN[e] = pN[e];
-  }
-  // coefficients of the strips that touch a body: four columns per 16-byte load, one chunk ahead.  The east face
-  // lx[i+1][j] is the west face of the row below, i.e. what lane+1 (one column behind) holds: no load for it.
-  F4 a_lw, a_ls, a_iv, b_lw, b_ls, b_iv;
-  float a_ln4 = 0.f, b_ln4 = 0.f;
-  const int icf = i < 0 ? 0 : (i > n_ + 1 ? n_ + 1 : i);  // every lane loads its own row (also the one below the strip)
-  const int cbase = icf * m + jo;
-#define MW_COEF(TAU, lw_, ls_, iv_, ln4_) \
-  {                                       \
-    int kk_ = cbase + (TAU);              \
-    kk_ = kk_ < 0 ? 0 : kk_;              \
-    lw_ = load4u(L.lx + kk_);             \
-    ls_ = load4u(L.ly + kk_);             \
-    iv_ = load4u(L.inv + kk_);            \
-    ln4_ = L.ly[kk_ + 4];                 \
-  }
-  if (!FAST) MW_COEF(0, a_lw, a_ls, a_iv, a_ln4)
-  float cur = 0.f;
-  const bool consumer = (wave > 0);
-  volatile lds_i *pprod = prog + (wave > 0 ? wave - 1 : 0);
-  int seen = gbase - 1;
-  if (consumer) __builtin_amdgcn_s_sleep(8);  // start about one chunk behind the producer: its progress word is then
-                                              // normally ahead of what is asked for and nobody spins
-  // one chunk: prefetch the operands of the next chunk into (nR,nE,nN / n_*), run 4 steps on (cR,cE,cN / c_*)
-#define MW_CHUNK(TAU0, cR, cE, cN, nR, nE, nN, c_lw, c_ls, c_iv, c_ln4, n_lw, n_ls, n_iv, n_ln4)                  \
-  {                                                                                                               \
-    const int tau0_ = (TAU0);                                                                                     \
-    const int q_ = tau0_ >> 2;                                                                                    \
-    if (consumer && q_ >= 1) { /* the previous sweep must have finished chunk q-1 (S = 8) */                      \
-      const int need_ = gbase + q_ - 1;                                                                           \
-      while (seen < need_) {                                                                                      \
-        __builtin_amdgcn_s_sleep(1);                                                                              \
-        seen = *pprod;                                                                                            \
-      }                                                                                                           \
-    }                                                                                                             \
-    asm volatile("" ::: "memory"); /* the prefetches below must not be hoisted above the wait (volatile orders only volatile) */ \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
-      nR[e] = pR[tau0_ + 4 + e];                                                                                  \
-      nE[e] = pE[tau0_ + 4 + e];                                                                                  \
-      nN[e] = pN[tau0_ + 4 + e];                                                                                  \
-    }                                                                                                             \
-    if (consumer) seen = *pprod; /* for the next chunk: usually already far enough */                             \
-    asm volatile("" ::: "memory");                                                                                \
-    float le4[4] = {0.f, 0.f, 0.f, 0.f};                                                                          \
-    if (!FAST) {                                                                                                  \
-      MW_COEF(tau0_ + 4, n_lw, n_ls, n_iv, n_ln4)                                                                 \
-      le4[0] = lane_next(c_lw.v[1]);                                                                              \
-      le4[1] = lane_next(c_lw.v[2]);                                                                              \
-      le4[2] = lane_next(c_lw.v[3]);                                                                              \
-      le4[3] = lane_next(n_lw.v[0]);                                                                              \
-    }                                                                                                             \
-    const int jb = tau0_ + jo;                                                                                    \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
-      float lw, le, ls, ln, iv;                                                                                   \
-      if (FAST) { /* out-of-domain neighbours read as d = 0: a boundary face may keep the uniform coefficient */  \
-        lw = le = ls = ln = cu;                                                                                   \
-        iv = iv0;                                                                                                 \
-        if (ZB) {                                                                                                 \
-          const int j = jb + e;                                                                                   \
-          iv = (j == 1) ? iv1 : ((j == m_) ? iv2 : iv0);                                                          \
-        }                                                                                                         \
-      } else {                                                                                                    \
-        lw = c_lw.v[e];                                                                                           \
-        le = le4[e];                                                                                              \
-        ls = c_ls.v[e];                                                                                           \
-        ln = (e < 3) ? c_ls.v[(e + 1) & 3] : c_ln4;                                                               \
-        iv = c_iv.v[e];                                                                                           \
-      }                                                                                                           \
-      const float prev = cur;                                                                                     \
-      const float dW = lane_prev(prev);                                                                           \
-      const float v = -(dW * lw + cE[e] * le + prev * ls + cN[e] * ln - cR[e]) * iv; /* MG.pde:84-88 */          \
-      const float v2 = sel_mask(v, cE[e], replay);                                                                \
-      cur = ((unsigned)(jb + e - 1) < m_on) ? v2 : 0.f;                                                           \
-      lds_f *w = ((unsigned)(jb + e - 1) < m_wr) ? (pW + tau0_ + e) : dmy;                                        \
-      *w = cur;                                                                                                   \
-    }                                                                                                             \
-    asm volatile("" ::: "memory"); /* the progress word goes out after the data */                                \
-    if (lane64 == 0) prog[wave] = gbase + q_;                                                                     \
-    asm volatile("" ::: "memory");                                                                                \
-  }
-  for (int tau0 = 0; tau0 < T; tau0 += 8) {
-    MW_CHUNK(tau0, aR, aE, aN, bR, bE, bN, a_lw, a_ls, a_iv, a_ln4, b_lw, b_ls, b_iv, b_ln4)
-    MW_CHUNK(tau0 + 4, bR, bE, bN, aR, aE, aN, b_lw, b_ls, b_iv, b_ln4, a_lw, a_ls, a_iv, a_ln4)
-  }
-#undef MW_CHUNK
-#undef MW_COEF
-}
-
-// One call = everything a level does on the way up, like mg_up_smooth, with the multi-wave smoother: strips of
-// H rows (H = LevelDesc.mw_H, chosen on the host so that both rings fit the workgroup's LDS).
-__device__ inline void mg_up_smooth_mw(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, double *sm,
-                                       float *rr_out, float *linf_out, ProfT &pf, float *xsum_out = nullptr,
-                                       const int rmode = 0) {
-  const int n = F.n, m = F.m, n_ = n - 2, m_ = m - 2;
-  const LevelDesc &D = *F.desc;
-  const int H = uni(D.mw_H), NR = H + 6;
-  float *dr = lds + kMwGuardLo, *rr = dr + NR * m + kMwGuardMid, *dummy = rr + NR * m + kMwGuardMid;
-  const int tid = threadIdx.x;
-  const int mc = Cc.m;
-  const int PW = m;
-  const int rstep = kThreads / m, cstep = kThreads - rstep * m;
-  const int r0 = tid / m, c0 = tid - r0 * m;
-  double rr_part = 0, xs_part = 0;
-  float linf = 0.f;
-  const int CPR = m_ >> 2;
-  const bool chunked = ((m_ & 3) == 0);
-  const DescU du = desc_u(D);
-  UpGeom U{&F, &Cc, &D, n, m, n_, m_, mc, PW, CPR, rr, dr, du};
-  U.NR = NR;
-  U.store_r = (rmode != 1);
-  U.update_x = (rmode != 2);
-  // a thread keeps its 4-column chunk and walks down the rows of its group: no division in the strip loops
-  const int ngrp = chunked ? (kThreads / CPR) : 1, rg = chunked ? (tid / CPR) : 0, c4 = chunked ? (tid - rg * CPR) : 0;
-  const bool grp_on = chunked && (rg < ngrp);
-  __syncthreads();
-  int gbase = 0;
-  if (tid < 4) ((lds_i *)(lds_f *)dummy)[64 + tid] = -1;  // progress words of the four waves
-  int loaded = 0;
-  for (int I0 = 1; I0 - 3 <= n_; I0 += H) {
-    const int hi = I0 + H;
-    const bool sp_fill = (hi + 1 >= du.sp_i0) && (loaded <= du.sp_i1);
-    if (chunked) {
-      if (grp_on)
-        for (int g = loaded + 1 + rg; g <= hi; g += ngrp) {
-          const FillIn in = fill_load(U, HASC, g, c4);
-          fill_apply(U, HASC, g, c4, in, sp_fill);
-        }
-    } else {
-      int g = loaded + 1 + r0, j = c0;
-      while (g <= hi) {
-        float rv = 0.f, dv = 0.f;
-        if (g <= n_ && j >= 1 && j <= m_) {
-          const int kk = g * m + j;
-          rv = F.r[kk];
-          float lw, le, ls, ln, iv;
-          if (sp_fill) {
-            lw = F.lx[kk];
-            le = F.lx[kk + m];
-            ls = F.ly[kk];
-            ln = F.ly[kk + 1];
-            iv = F.inv[kk];
-          } else {
-            coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
-          }
-          if (HASC) {  // r -= A * prolongate(coarse.x)   (PoissonMatrix.pde:53-64 order)
-            const float dc = prolong_at(Cc.x, mc, g, j, n_, m_);
-            const float dw = prolong_at(Cc.x, mc, g - 1, j, n_, m_), de = prolong_at(Cc.x, mc, g + 1, j, n_, m_);
-            const float ds = prolong_at(Cc.x, mc, g, j - 1, n_, m_), dn = prolong_at(Cc.x, mc, g, j + 1, n_, m_);
-            const float diag = -(lw + le + ls + ln);
-            rv = rv - (dc * diag + dw * lw + de * le + ds * ls + dn * ln);
-          }
-          dv = rv * iv;  // MG.pde:80
-        }
-        const int sl = (g % NR) * PW + j;
-        rr[sl] = rv;
-        dr[sl] = dv;
-        g += rstep;
-        j += cstep;
-        if (j >= m) {
-          j -= m;
-          ++g;
-        }
-      }
-    }
-    loaded = hi;
-    lds_barrier();
-    if (need_r) pf.mark(PF_UP0);
-    {
-      const int lm = n_ - I0 + 4, Lmax = lm < H ? lm : H;
-      const bool special = (hi >= du.sp_i0) && (I0 - 4 <= du.sp_i1);
-      gbase += 4096;  // chunk numbers never repeat within a level call, so the progress words need no reset
-      if (H <= 30) {  // two sweeps per wave
-        if (special)
-          gs_multiwave<false, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-        else if (du.zb)
-          gs_multiwave<true, true, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-        else
-          gs_multiwave<true, false, 2>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-      } else {
-        if (special)
-          gs_multiwave<false, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-        else if (du.zb)
-          gs_multiwave<true, true, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-        else
-          gs_multiwave<true, false, 1>(F, rr, dr, dummy, NR, I0, Lmax, gbase);
-      }
-      lds_barrier();  // every sweep of the strip is complete
-    }
-    if (need_r) pf.mark(PF_GS0);
-    // ---- exit: rows whose d (and d of both row neighbours) is final: d.setBC(); increment() ----
-    const int e0 = (I0 - 4 < 1) ? 1 : I0 - 4, e1 = (I0 + H - 4 >= n_) ? n_ : I0 + H - 5;
-    const bool sp_exit = (e1 + 1 >= du.sp_i0) && (e0 - 1 <= du.sp_i1);
-    if (chunked) {
-      if (grp_on)
-        for (int g = e0 + rg; g <= e1; g += ngrp) {
-          const ExitIn in = exit_load(U, HASC, g, c4);
-          exit_apply(U, HASC, need_r, g, c4, in, sp_exit, rr_part, xs_part, linf);
-        }
-    } else {
-      int g = e0 + r0, j = c0;
-      while (g <= e1) {
-        if (j >= 1 && j <= m_) {
-          const int kk = g * m + j;
-          const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > n_) ? n_ : g + 1;
-          const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > m_) ? m_ : j + 1;
-          const int sl = (g % NR) * PW;
-          const float d = dr[sl + j];
-          if (need_r) {
-            const float dW = dr[(gw % NR) * PW + j], dE = dr[(ge % NR) * PW + j];
-            const float dS = dr[sl + js], dN = dr[sl + jn];
-            float lw, le, ls, ln, iv;
-            if (sp_exit) {
-              lw = F.lx[kk];
-              le = F.lx[kk + m];
-              ls = F.ly[kk];
-              ln = F.ly[kk + 1];
-            } else {
-              coef_analytic(D, du, g, j, n_, m_, lw, le, ls, ln, iv);
-            }
-            const float diag = -(lw + le + ls + ln);
-            const float rn = rr[sl + j] - (d * diag + dW * lw + dE * le + dS * ls + dN * ln);  // MG.pde:96
-            F.r[kk] = rn;
-            const float pr = rn * rn;
-            rr_part += (double)pr;
-            linf = jmax(linf, jabs(rn));
-          }
-          float xo = F.x[kk];
-          if (HASC) xo = xo + prolong_at(Cc.x, mc, g, j, n_, m_);
-          const float xnew = xo + d;
-          F.x[kk] = xnew;
-          if (need_r) xs_part += (double)xnew;
-          const bool gi0 = (g == 1), gi1 = (g == n_), gj0 = (j == 1), gj1 = (j == m_);
-          if (gi0 | gi1 | gj0 | gj1) {
-            const float dp = HASC ? prolong_at(Cc.x, mc, g, j, n_, m_) : 0.f;
-#define GHOST_UPD(GI, GJ)            \
-  {                                  \
-    float xg = F.x[(GI) * m + (GJ)]; \
-    if (HASC) xg = xg + dp;          \
-    F.x[(GI) * m + (GJ)] = xg + d;   \
-  }
-            if (gi0) GHOST_UPD(0, j)
-            if (gi1) GHOST_UPD(n - 1, j)
-            if (gj0) GHOST_UPD(g, 0)
-            if (gj1) GHOST_UPD(g, m - 1)
-            if (gi0 && gj0) GHOST_UPD(0, 0)
-            if (gi0 && gj1) GHOST_UPD(0, m - 1)
-            if (gi1 && gj0) GHOST_UPD(n - 1, 0)
-            if (gi1 && gj1) GHOST_UPD(n - 1, m - 1)
-#undef GHOST_UPD
-          }
-        }
-        g += rstep;
-        j += cstep;
-        if (j >= m) {
-          j -= m;
-          ++g;
-        }
-      }
-    }
-    lds_barrier();  // the next strip's fill re-uses ring slots this exit has just read
-    if (need_r) pf.mark(PF_INC0);
-  }
-  __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
-  if (need_r && rmode != 2) {
-    *rr_out = uni((float)block_sum_d(rr_part, sm));
-    *linf_out = uni(block_max_f(linf, sm));
-    if (xsum_out) *xsum_out = uni((float)block_sum_d(xs_part, sm));
-  }
-}
+#if AFC_DIAG
+#include "bdim_v2_multiwave.h"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Fused head of the pressure solve on the finest level (MG.pde:51 + first smooth(0) + restrict):
@@ -3643,10 +2966,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
     } else if (!AFC_RB) {
       const Lv Lk = uni(make_level(P, e, kc));  // coarsest: coarse.smooth(its), MG.pde:73
       for (int q = threadIdx.x; q < Lk.n * Lk.m; q += kThreads) Lk.x[q] = 0.f;  // MG.pde:56
-      if (!(AFC_DBG_OF(P) & 4))
-        mg_up_smooth<16>(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
-      else
+#if AFC_DIAG
+      if (AFC_DBG_OF(P) & 4)
         mg_up_smooth_mw(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
+      else
+#endif
+        mg_up_smooth<16>(false, Lk, Lk, false, lds, sm, &rr, &linf, pf);
       pf.mark(16 + kc);
     }
     // (perf mode: the loop starts at the coarsest level itself -- coarse.smooth(its) from x = 0, the same call with
@@ -3678,9 +3003,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
         mg_up_rbw(hasc, F, Cc, l == 0, lds, &rr, &linf, &xsum, lazy_r ? 1 : 0);
       else
 #endif
+#if AFC_DIAG
       if (AFC_DBG_OF(P) & 4)
         mg_up_smooth_mw(hasc, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-      else if (pipe)
+      else
+#endif
+      if (pipe)
         mg_up_pipe(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else if (H0 != 16 && l == 0)
         mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
@@ -3688,9 +3016,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
         mg_up_smooth<16>(hasc, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       if (lazy_r && !(rr < P.mg_tol) && iter < P.mg_max_iters) {
         float rr2, linf2;  // replay the level: identical d, r -= A d stored this time
+#if AFC_DIAG
         if (AFC_DBG_OF(P) & 4)
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
-        else if (pipe)
+        else
+#endif
+        if (pipe)
           mg_up_pipe(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
           mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
