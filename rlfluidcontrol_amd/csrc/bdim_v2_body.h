@@ -1723,6 +1723,8 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
 // The fill of group q-1 overwrites ring slots that the exits of groups q-2, q-1 (another wave's tasks, earlier ones: xf
 // flags) and q (this task) read -- an exit reads one column to either side of its chunk.
 // For levels of 16-column groups and 16-row strips (m_ % 16 == 0, n_ % 16 == 0); the caller keeps mg_up_smooth otherwise.
+// The protocol on its own -- who may touch which ring cell when -- is checked by a discrete-event model under random and
+// adversarial schedules, with weakened variants as counter-examples: tests/test_pipe_protocol_model.py.
 __device__ __host__ __forceinline__ bool up_pipe_shape_ok(int n, int m) {
   return ((m - 2) & 15) == 0 && ((n - 2) & 15) == 0 && (m - 2) >= 32 && (m - 2) <= 256 && (n - 2) >= 32;
 }

@@ -222,6 +222,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_project(StepParams P, i
   const int m_ = P.m - 2;
   int it;
   // TAG 1: instances of their own (see advdif_v2's TAG); the column count selects what the step kernel of this grid runs
+  // (C only enters project_v2 / mg_solve_v2 through up_strip_h(C), the strip height of the finest up-leg, which is 16 for
+  // C = 1 and C = 2 alike: grids of up to 64 columns run the same code under either)
 #define PROJ(c)                                                                                                       \
   it = afc::AFC_MODE_NS::project_v2<c, 1>(false, P, 0, G(P.fx), G(P.fy), G(P.p), G(P.d), &shift, nullptr, nullptr, \
                                            nullptr, nullptr, sm, &l, pf, lds_dyn)
