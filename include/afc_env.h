@@ -103,7 +103,7 @@ typedef struct afc_config {
                            convergent smoother -- VALIDATION ONLY: results agree with the reference to the tolerance
                            enforced in tests/test_gpu_perfmode.py (|du|, |dv| <= 1e-3, |dp| <= 2e-2, |dC| <= 3e-3 over 16
                            steps from init.bdim; 1.5 x that for u, v, p at 64 steps), not bit for bit, and on this machine
-                           it is SLOWER than mode 0 (round 5: 510 k against 682 k env-sim-steps/s).
+                           it is SLOWER than mode 0 (round 5: 509 k against 685 k env-sim-steps/s).
                            The finest level's up-leg runs as register-resident row pipelines (mg_up_rbw; AFC_RBW=<mask
                            of levels> in the environment selects others, 0 none: same bits).  No diagnostics:
                            afc_create refuses it together with stagger_us != 0 or reserved[0] != 0, afc_profile_phases

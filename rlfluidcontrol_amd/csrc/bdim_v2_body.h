@@ -955,8 +955,8 @@ __device__ __forceinline__ void pipe_wait_fill(const lds_i *ff, int lo, int hi, 
 // a helper wave waits until a (wave-uniform) word has reached `need`
 __device__ __forceinline__ void pipe_wait_word(const lds_i *w, int need) {
 #ifndef AFC_PIPE_SLEEP
-#define AFC_PIPE_SLEEP 1
-#endif
+#define AFC_PIPE_SLEEP 4  // x 64 clocks between two looks at a flag: 1 / 4 / 8 / 16 measured 24.08 / 24.00 / 24.00 / 24.01 ms per launch at
+#endif                    // 1024 envs, 16.43 / 16.38 / 16.50 / 16.58 at 512, 11.52 / 11.50 / 11.54 / 11.69 for one env (same memory)
   while (uni(*(volatile const lds_i *)w) < need) __builtin_amdgcn_s_sleep(AFC_PIPE_SLEEP);
   asm volatile("" ::: "memory");
 }
