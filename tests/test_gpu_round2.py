@@ -389,3 +389,43 @@ def test_two_gpu_gather_every_rank_sees_the_same_batch():
     assert np.array_equal(res[0][2], res[1][2])        # identical gathered (obs, reward, done) on both ranks
     obs = res[0][2][:, :16].reshape(3, 8, 2)
     assert not np.array_equal(obs[2, :4], obs[2, 4:])  # the two shards ran different actions
+
+
+def test_pipelined_upleg_at_full_occupancy_is_deterministic_and_equals_the_barrier_form(envmod):
+    """race detector for mg_up_pipe (waves hand rows over through LDS flags instead of workgroup barriers) under the
+    load it ships for: 1024 envs, random actions, 8 agent steps -- two runs of the shipped kernels on the same inputs
+    must agree bit for bit (a timing-dependent hazard would not), and in parity mode the shipped kernels must agree bit
+    for bit with the barrier form (dbg bit 8, diagnostic instantiation): every observation of every env at every agent
+    step, the multigrid iteration histogram and the final fields of 32 envs.  (tools/pipe_soak.py: the same over any
+    number of agent steps; tests/test_pipe_protocol_model.py: the protocol itself on the CPU.)"""
+    E, N = 1024, 8
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wake_res16_re100.npz"))
+
+    def run(dbg, exact):
+        g = envmod.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=dbg, exact_sums=exact)
+        g.set_reset_state(z["u"], z["v"], z["p"])
+        g.reset()
+        rng = np.random.default_rng(7)
+        rec = []
+        for _ in range(N):
+            obs, rew, done, ns = g.agent_step(rng.uniform(-1, 1, (E, 2)).astype(np.float32))
+            rec.append((obs.copy(), rew.copy(), ns.copy()))
+        st = [g.get_state(e) for e in range(0, E, 32)]
+        h = g.mg_histogram()
+        g.close()
+        return rec, st, h
+
+    def same(a, b):
+        (ra, sa, ha), (rb, sb, hb) = a, b
+        assert np.array_equal(ha, hb)
+        for (o1, w1, n1), (o2, w2, n2) in zip(ra, rb):
+            assert np.array_equal(n1, n2) and np.array_equal(o1.view(np.uint32), o2.view(np.uint32))
+            assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+        for x, y in zip(sa, sb):
+            for f1, f2 in zip(x, y):
+                assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+    a1 = run(0, 0)
+    same(a1, run(0, 0))
+    assert a1[2][1:].sum() > 0  # some solves took a second V-cycle: the replay of the finest up-leg ran too
+    same(run(0, 1), run(256, 1))
