@@ -183,6 +183,7 @@ struct afc_env {
   int32_t *d_i32 = nullptr;
   long long *d_stamps = nullptr;
   size_t lds_bytes = 0;
+  size_t lds_bytes_step = 0;  // dynamic LDS of the shipped / perf step kernels (>= lds_bytes: + the fused advection's three row slots)
   StepParams *d_P = nullptr;  // device copy of P for the step kernels
   bool p_dirty = true;
   int cpl = 0;  // kernel instantiation: columns per lane (0 = reference kernels)
@@ -430,7 +431,32 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     if (P.impl != 0 && (one_tile || two_tiles) && a3 <= fl && rows_per_wave >= 8) P.adv_ns = afc::prod::kAdvNS;
   }
 
-  P.up2_unused = 0;
+  // advdif_v3f (the predictor's projection tail inside the corrector's advection): one more ring row per wave.  The
+  // diagnostic instantiation never runs it and keeps the smaller region (its static part is 2 KB larger); every other
+  // "does it fit" above and below is answered for the smaller region.
+  env->lds_bytes_step = env->lds_bytes;
+  P.fuse_tail = 0;
+  {
+    const int m_ = sf.m - 2, cplv = (m_ + 63) / 64;
+    const size_t af = cplv <= 2 ? (size_t)afc::prod::advf_lds_floats(cplv) * sizeof(float) : 0;
+    // Measured on the same memory (tools/ab_inproc.py --share-slab): -1.1 % per launch with four workgroups per CU
+    // (1024 envs), -0.1 % with two, +1.7 % with one -- a wave alone on its SIMD has nobody to hide the projection's
+    // LDS round trips behind.  So by default: fused where a launch puts more than two workgroups on a CU
+    // (afc_config.fuse_tail: 1 = wherever the shape allows, -1 = never).
+    int cus = 256;
+    {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    bool want = cfg->fuse_tail > 0 || (cfg->fuse_tail == 0 && (long long)env->E > 2ll * cus);
+#if AFC_DEVHOOKS
+    if (const char *ft = getenv("AFC_FUSE_TAIL")) want = atoi(ft) != 0;  // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1
+#endif
+    if (P.impl != 0 && P.adv_ns && cplv <= 2 && afc::prod::advf_shape_ok(sf.n, sf.m, cplv) && af + 512 <= 40960 && want) {
+      P.fuse_tail = 1;
+      if (af > env->lds_bytes_step) env->lds_bytes_step = af;
+    }
+  }
   P.head_v3 = (P.impl != 0 && sf.m == 130 && ((sf.n - 2) & 7) == 0 &&
                (size_t)afc::prod::kHeadLdsFloats * sizeof(float) <= env->lds_bytes) ? 1 : 0;
   P.head_v4 = (P.impl != 0 && afc::prod::head4_shape_ok(sf.n, sf.m) &&
@@ -626,9 +652,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_upload(env, &P.fs, fs);
 
   const size_t E = (size_t)env->E;
-  AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
+  AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d, &P.qx, &P.qy};
   {
-    // The per-env state lives in ONE allocation (the eleven fine fields back to back, then the coarse scratch): the
+    // The per-env state lives in ONE allocation (the thirteen fine fields back to back, then the coarse scratch): the
     // same library ran 7 % apart between env instances whose arrays came from separate hipMalloc calls (same box, same
     // process, launches interleaved: tools/ab_inproc.py) -- where the driver happens to place a dozen 140 MB buffers
     // decides how the streams of a phase fall on the memory channels / translation fragments.
@@ -654,7 +680,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     } else {
       float *slab = nullptr;
       const size_t scz = ((E * sizeof(EnvScalars) + 255) / 256) * 64;  // the per-env scalars, in floats, at the end of the slab
-      const size_t total = kFront + 11 * fsz + csz + scz;
+      const size_t total = kFront + 13 * fsz + csz + scz;
       // development (tools/ab_inproc.py --share-slab): an instance adopts the slab of another instance of the same shape,
       // so that builds are compared on the SAME memory (placements of the fast kind still differ by +-0.5 %)
       // (compiled in with -DAFC_DEVHOOKS=1 only -- tools/build_variant.sh; the shipped library takes no pointers from
@@ -767,10 +793,10 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           setenv("AFC_LAST_SLAB", buf, 1);
         }
 #endif
-        P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + 11 * fsz + csz);
+        P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + 13 * fsz + csz);
         size_t k = 0;
         for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + kFront + (k++) * fsz);
-        P.coarse = (AFC_AS1 float *)(slab + kFront + 11 * fsz);
+        P.coarse = (AFC_AS1 float *)(slab + kFront + 13 * fsz);
       }
     }
   }
@@ -1042,8 +1068,8 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
   switch (env->cpl == 0 ? 1 : launch_mode(env)) {  // the reference kernels (cpl 0) live in the diagnostic unit
     case 1: afc::launch_sim_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce); break;
-    case 2: afc::launch_sim_step_perf(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce); break;
-    default: afc::launch_sim_step_prod(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce);
+    case 2: afc::launch_sim_step_perf(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dxi, dforce); break;
+    default: afc::launch_sim_step_prod(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dxi, dforce);
   }
   int rc = launch_check("k_sim_step");
   if (rc) return rc;
@@ -1082,8 +1108,8 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   if (env->P.gate_limit == 15) HIP_TRY(hipMemsetAsync(G(env->P.gate), 0, 64 * sizeof(int), env->stream));
   switch (env->cpl == 0 ? 1 : launch_mode(env)) {
     case 1: afc::launch_agent_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
-    case 2: afc::launch_agent_step_perf(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
-    default: afc::launch_agent_step_prod(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps);
+    case 2: afc::launch_agent_step_perf(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
+    default: afc::launch_agent_step_prod(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps);
   }
   int rc = launch_check("k_agent_step");
   if (rc) return rc;
@@ -1442,6 +1468,11 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   if (iters) *iters = it;
   if (resid_linf) *resid_linf = l;
   return AFC_OK;
+}
+
+int afc_fused_tail(const afc_env *env) {
+  if (!env) return fail(AFC_EINVAL, "afc_fused_tail: null");
+  return env->P.fuse_tail != 0 ? 1 : 0;
 }
 
 int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *median_gbs) {

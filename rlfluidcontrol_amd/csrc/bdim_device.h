@@ -92,7 +92,7 @@ struct StepParams {
   const AFC_AS1 float *seg_l, *seg_nx, *seg_ny;
   int nseg;
   // per-env state [E][Ns]
-  AFC_AS1 float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d;
+  AFC_AS1 float *ux, *uy, *p, *u0x, *u0y, *usx, *usy, *fx, *fy, *r, *d, *qx, *qy;
   AFC_AS1 float *coarse;  // [E][Cs]: r_l | x_l | d_l for l >= 1
   AFC_AS1 EnvScalars *sc;
   AFC_AS1 long long *stamps;  // optional [32] accumulated wall-clock ticks per phase (env 0 only; diagnostics)
@@ -111,7 +111,7 @@ struct StepParams {
   int adv_ns;          // ring depth (rows) of advdif_v3's per-wave row pipelines; 0 = use advdif_v2
   int head_v3;         // 1: the barrier-free head of the pressure solve (grids of 128 interior columns)
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
-  int up2_unused;      // (was: the two-strip up-leg experiment, removed in round 5; keeps the layout of the block)
+  int fuse_tail;       // 1: the predictor's projection tail runs inside the corrector's advection (advdif_v3f), its result in qx / qy
   int bottom_lb;       // first multigrid level of the LDS-resident bottom of the V-cycle (mg_bottom); 0 = none
   int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows

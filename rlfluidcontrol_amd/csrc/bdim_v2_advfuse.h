@@ -1,0 +1,383 @@
+// THE CORRECTOR'S ADVECTION WITH THE PREDICTOR'S PROJECTION TAIL INSIDE IT (included by bdim_v2_body.h, inside the
+// namespace of the instantiation).
+//
+// BDIM.update() ends with u.project: u -= c grad(p + s), u.setBC() (VectorField.pde:136-140); BDIM.update2() begins with
+// AdvDif of that field (BDIM.pde:90-93, VectorField.pde:170-179).  As two passes (project_tail_v2, then advdif_v3) the
+// projected field is written to memory (2 floats per cell) and read back (2 floats) a gigabyte of other traffic later.
+// Here the advection's row pipelines stage the RAW rows (the field as forcing + setBC left it in front of the solve), and
+// each wave projects a row IN ITS LDS RING, two rows ahead of the stencil that reads it:
+//
+//   * the raw velocity rows arrive by LDS-DMA exactly as advdif_v3's source rows do; so does the row of p, one row
+//     ahead, into a single row slot (p of the row above is the previous row's, kept in registers), and -- for rows that
+//     cross a body -- the two rows of face coefficients.  Nothing comes through registers asynchronously: a load whose
+//     destination the compiler may copy or spill before the hand-placed wait is a race (tried: loads by inline assembly
+//     into tied operands -- the compiler moved the set between registers while the load was in flight).  The three row
+//     slots are paid for by the base rows, which are single-buffered here (copied right after their use, one
+//     iteration ahead): 19 rows per wave instead of 18
+//   * the projected row is written back into the ring slot (with the wall columns setBC gives it) and -- by the wave
+//     that OWNS the row -- to the field `q`, which the Heun average at the end of the corrector reads as `us`
+//     (BDIM.pde:95-96).  q is a field of its own: the raw field stays intact, so the two halo rows either side of a
+//     wave's quarter are projected a second time by the neighbour, in its own ring, with the same operands -- no flags,
+//     no ordering between waves, no barrier
+//   * what setbc_rows does after the tail moves to the owners of rows 1 and n-2: row 0 = the projected row 1, then
+//     u.x of row 1 = 1 (inflow); row n-1 = the projected row n-2 with the outflow correction 1 - mean(row n-2), the
+//     mean added in the reference's order (Field.pde:302-318) through v_readlane
+//
+// Same operands, same operations, same order as project_tail_v2 + setbc_rows + advdif_v3: the bits do not change.
+// All waits are counted vmcnt waits formed from a running count of the wave's issued vector-memory operations and the
+// count at the operation waited for (`issued - tag`): the wave's operations complete in order.
+//
+// One column tile only (grids of at most 64*C interior columns: 256x128, 128x64), >= 8 rows per wave, folded walls.
+constexpr int kAdvfNS = 6;  // ring rows per component: i-2 .. i+3 (the raw copies run ONE row less ahead than advdif_v3's: the row after next)
+__device__ __host__ __forceinline__ int advf_lds_floats(int C) { return 4 * (2 * kAdvfNS + 7) * (64 * C + 4) + 4; }
+__device__ __host__ __forceinline__ bool advf_shape_ok(int n, int m, int C) {
+  return (C == 1 || C == 2) && (m - 2) <= 64 * C && ((m - 2) % C) == 0 && ((n - 2) & 3) == 0 && (n - 2) >= 4 * 8;
+}
+
+template <int C>
+__device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
+                                        const float *__restrict__ bx, const float *__restrict__ by,
+                                        float *__restrict__ dx, float *__restrict__ dy, float *lds,
+                                        const float *__restrict__ pp, const float shift, float *__restrict__ qx,
+                                        float *__restrict__ qy) {
+  static_assert(C == 1 || C == 2, "one column tile of 64*C columns");
+  constexpr int PR = 64 * C + 4, NS = kAdvfNS;
+  constexpr unsigned PRB = PR * 4u;
+  constexpr int YO = NS * PR;
+  constexpr int ST = 4;
+  const int n = uni(P.n), n_ = n - 2, m = uni(P.m), m_ = m - 2;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int W = m_, lanes_on = W / C;
+  const int LQ = (W + 7) >> 2;
+  const int RPW = (n_ + 3) >> 2;
+  const int i_first = 1 + wave * RPW, i_last = (i_first + RPW - 1 < n_) ? i_first + RPW - 1 : n_;
+  const unsigned ring = uni((int)(((lds_addr(lds) + 15u) & ~15u) + (unsigned)wave * ((2 * NS + 7) * PRB)));
+  // base x, y of even rows | of odd rows | p, cx, cy
+  const unsigned bslot = ring + (unsigned)(2 * NS) * PRB, pslot = bslot + 4u * PRB;
+  const float nu = uni(P.nu), dt = uni(P.dt);
+  const float *sxc = sx - 1, *syc = sy - 1, *bxc = bx - 1, *byc = by - 1;  // ring index 0 is "column -1"
+  const float *ppc = uni(pp) - 1;
+  const int sp0 = uni(P.lev[0].sp_i0), sp1 = uni(P.lev[0].sp_i1);
+  const float cu = uni(P.lev[0].cu);
+  const float *pcx = uni(G(P.cx)) - 1, *pcy = uni(G(P.cy)) - 1;
+  if (i_first <= i_last) {
+    const int r_hi = (i_last + 2 < n - 1) ? i_last + 2 : n - 1;  // last row the stencils of this wave read
+    const int p_hi = (r_hi < n_) ? r_hi : n_;                    // last row this wave stages and projects
+    const int g0 = (i_first - 2 > 1) ? i_first - 2 : 1;          // first row it projects
+    int issued = 0;                                              // vector-memory operations of this wave so far
+    int r_next = i_first - 2, s_next = 0;
+#define ADVF_STAGE()                                                                   \
+  {                                                                                    \
+    if (r_next >= 1 && r_next <= p_hi) {                                               \
+      const unsigned ln_ = lane_fresh();                                               \
+      if (ln_ < (unsigned)LQ) {                                                        \
+        const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                  \
+        lds_dma16(sxc, so_, ring + (unsigned)s_next * PRB);                            \
+        lds_dma16(syc, so_, ring + (unsigned)(s_next + NS) * PRB);                     \
+      }                                                                                \
+      issued += 2;                                                                     \
+    }                                                                                  \
+    ++r_next;                                                                          \
+    s_next = (s_next + 1 == NS) ? 0 : s_next + 1;                                      \
+  }
+#define ADVF_BASE(row)                                                                 \
+  {                                                                                    \
+    const unsigned ln_ = lane_fresh();                                                 \
+    if (ln_ < (unsigned)LQ) {                                                          \
+      const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
+      const unsigned lb_ = bslot + (unsigned)(2 * ((row) & 1)) * PRB;                  \
+      lds_dma16(bxc, so_, lb_);                                                        \
+      lds_dma16(byc, so_, lb_ + PRB);                                                  \
+    }                                                                                  \
+    issued += 2;                                                                       \
+  }
+    // p of row g (and, for a row that crosses a body, its face coefficients) into the wave's three row slots
+#define ADVF_ISSUE(g)                                                                  \
+  {                                                                                    \
+    const unsigned ln_ = lane_fresh();                                                 \
+    const unsigned so_ = 4u * (unsigned)((g) * m) + 16u * ln_;                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slots' readers are done */ \
+    if (ln_ < (unsigned)LQ) lds_dma16(ppc, so_, pslot);                                \
+    issued += 1;                                                                       \
+    if ((g) >= sp0 && (g) <= sp1) {                                                    \
+      if (ln_ < (unsigned)LQ) {                                                        \
+        lds_dma16(pcx, so_, pslot + PRB);                                              \
+        lds_dma16(pcy, so_, pslot + 2u * PRB);                                         \
+      }                                                                                \
+      issued += 2;                                                                     \
+    }                                                                                  \
+  }
+    float pw[C];  // p of the row above the next row to project (this lane's columns)
+    // Row g of the raw field, in ring slot s, becomes the projected row: VectorField.pde:138 + the wall columns of
+    // Field.pde:217-224 (as project_tail_v2 folds them) + the row part of setBC for rows 1 and n-2 (setbc_rows)
+    auto project_row = [&](const int g, const int s, const bool own, const unsigned prow) {
+      const unsigned ln_ = lane_fresh();
+      const int j0 = 1 + C * (int)ln_;
+      lds_f *ru = (lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)s * PRB);
+      float u[C], v[C], pc[C], ps0, cx[C], cy[C];
+      const lds_f *rp = (const lds_f *)(uintptr_t)(prow + 4u * (unsigned)(j0 + 1));
+      const lds_f *rc = (const lds_f *)(uintptr_t)(pslot + PRB + 4u * (unsigned)(j0 + 1));
+      if constexpr (C == 2) {
+        const f2 a = *(const lds_f2a *)ru, b = *(const lds_f2a *)(ru + YO), c = *(const lds_f2a *)rp;
+        u[0] = a.x, u[1] = a.y, v[0] = b.x, v[1] = b.y, pc[0] = c.x, pc[1] = c.y;
+      } else {
+        u[0] = ru[0], v[0] = ru[YO], pc[0] = rp[0];
+      }
+      ps0 = rp[-1];
+      if (g >= sp0 && g <= sp1) {  // rows that cross a body: the real coefficient arrays
+        if constexpr (C == 2) {
+          const f2 a = *(const lds_f2a *)rc, b = *(const lds_f2a *)(rc + PR);
+          cx[0] = a.x, cx[1] = a.y, cy[0] = b.x, cy[1] = b.y;
+        } else {
+          cx[0] = rc[0], cy[0] = rc[PR];
+        }
+      } else {  // verified on the host: every face coefficient of the row equals cu (LevelDesc)
+#pragma unroll
+        for (int e = 0; e < C; ++e) cx[e] = cy[e] = cu;
+      }
+      float un[C], vn[C], vs[C];
+#pragma unroll
+      for (int e = 0; e < C; ++e) {
+        const float pcs = pc[e] + shift, pws = pw[e] + shift;
+        const float pss = ((e > 0) ? pc[e > 0 ? e - 1 : 0] : ps0) + shift;
+        const float gx = pcs - pws, gy = pcs - pss;  // Field.pde:76-77
+        un[e] = u[e] + cx[e] * (gx * -1.f);          // VectorField.pde:138
+        vn[e] = v[e] + cy[e] * (gy * -1.f);
+        vs[e] = vn[e];
+        pw[e] = pc[e];
+      }
+      const bool first = (ln_ == 0u), last = (ln_ == (unsigned)(lanes_on - 1)), on = ln_ < (unsigned)lanes_on;
+      if (first) vs[0] = 0.f;
+      const float wu = first ? un[0] : un[C - 1], wv = first ? vn[0] : 0.f;  // the lane's wall column (lane 0: 0, last lane: m-1)
+      const int wi = first ? -1 : C;                                          // ... and its place in the ring row
+      auto put_ring = [&](lds_f *r, const float *xu, const float xw) {
+        if (on) {
+#pragma unroll
+          for (int e = 0; e < C; ++e) r[e] = xu[e], r[YO + e] = vs[e];
+          if (first || last) r[wi] = xw, r[YO + wi] = wv;
+        }
+      };
+      auto put_field = [&](const int row, const float *xu, const float xw) {
+        if (first || last) {
+          const unsigned gb = 4u * (unsigned)(row * m + (first ? 0 : m - 1));
+          st1b(qx, gb, xw);
+          st1b(qy, gb, wv);
+        }
+        if (on) {
+          const unsigned ob = 4u * (unsigned)(row * m + j0);
+          __builtin_memcpy((char *)qx + ob, xu, sizeof(float) * C);
+          __builtin_memcpy((char *)qy + ob, vs, sizeof(float) * C);
+        }
+        issued += ST;
+      };
+      if (g == 1) {  // setBC: row 0 = row 1, then u.x[1][.] = 1 (Field.pde:207-212)
+        float one[C];
+#pragma unroll
+        for (int e = 0; e < C; ++e) one[e] = 1.f;
+        put_ring((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s == 0 ? NS - 1 : s - 1) * PRB), un, wu);
+        put_ring(ru, one, 1.f);
+        if (own) {
+          put_field(0, un, wu);
+          put_field(1, one, 1.f);
+        }
+      } else {
+        put_ring(ru, un, wu);
+        if (own) put_field(g, un, wu);
+      }
+      if (g == n_) {  // row n-1 = row n-2, u.x with the flux correction 1 - mean (Field.pde:213-216, 302-318: in this order)
+        float sum = 0;
+        for (int l = 0; l < lanes_on; ++l) {
+#pragma unroll
+          for (int e = 0; e < C; ++e)
+            sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, un[e]), l));
+        }
+        sum /= (float)(m - 2);
+        const float corr = 1.f - sum;
+        float uc[C];
+#pragma unroll
+        for (int e = 0; e < C; ++e) uc[e] = un[e] + corr;
+        put_ring((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s + 1 == NS ? 0 : s + 1) * PRB), uc, wu);
+        if (own) put_field(n - 1, uc, wu);
+      }
+    };
+    // ---- prologue: raw rows i_first-2 .. i_first+2 staged and projected; then rows i_first+3, i_first+4, base row
+    // i_first and p of row i_first+3 on their way.  The up to six rows of p the five projections need (g0-1 .. i_first+2)
+    // arrive TOGETHER, in the six row slots that are still idle -- ring slot 5 of both components and the four base
+    // slots -- so that the prologue is one round trip plus one per row that crosses a body (the single pair of
+    // coefficient slots), not one per row. ----
+    for (int q = 0; q < 5; ++q) ADVF_STAGE()
+    {
+      const unsigned ln_ = lane_fresh();
+      for (int g = g0 - 1; g <= i_first + 2; ++g) {
+        const int k = g - (i_first - 3);  // 0 .. 5
+        const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
+        if (ln_ < (unsigned)LQ) lds_dma16(ppc, 4u * (unsigned)(g * m) + 16u * ln_, slot);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int k0 = (g0 - 1) - (i_first - 3);
+      const unsigned slot0 = (k0 < 2) ? ring + (unsigned)(5 + k0 * NS) * PRB : bslot + (unsigned)(k0 - 2) * PRB;
+      const lds_f *rp = (const lds_f *)(uintptr_t)(slot0 + 4u * (unsigned)(2 + C * (int)ln_));
+#pragma unroll
+      for (int e = 0; e < C; ++e) pw[e] = rp[e];
+    }
+    for (int g = g0; g <= i_first + 2; ++g) {
+      const int k = g - (i_first - 3);
+      const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
+      if (g >= sp0 && g <= sp1) {
+        const unsigned ln_ = lane_fresh();
+        const unsigned so_ = 4u * (unsigned)(g * m) + 16u * ln_;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ln_ < (unsigned)LQ) {
+          lds_dma16(pcx, so_, pslot + PRB);
+          lds_dma16(pcy, so_, pslot + 2u * PRB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      project_row(g, g - (i_first - 2), g >= i_first, slot);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the readers of the borrowed slots are done
+    ADVF_STAGE()  // row i_first+3
+    ADVF_BASE(i_first)
+    int tag_b = issued;  // base row i
+    ADVF_ISSUE(i_first + 3)
+    int tag_p = issued;
+    f2 fE2[C];
+    int s0 = 0;  // ring slot of row i-2
+    for (int i = i_first; i <= i_last; ++i) {
+      const int t = i - i_first;
+      int tag_bn = tag_b;
+      if (i < i_last) {
+        ADVF_BASE(i + 1)
+        tag_bn = issued;
+      }
+      if (t > 0) ADVF_STAGE()  // raw row i+4 replaces row i-2
+      const int j0 = 1 + C * (int)lane_fresh();
+      const unsigned lo = ring + 4u * (unsigned)(j0 + 1);
+      const int s1 = (s0 + 1 >= NS) ? s0 + 1 - NS : s0 + 1, s2 = (s0 + 2 >= NS) ? s0 + 2 - NS : s0 + 2,
+                s3 = (s0 + 3 >= NS) ? s0 + 3 - NS : s0 + 3, s4 = (s0 + 4 >= NS) ? s0 + 4 - NS : s0 + 4,
+                s5 = (s0 + 5 >= NS) ? s0 + 5 - NS : s0 + 5;
+      const lds_f *r1 = (const lds_f *)(uintptr_t)(lo + (unsigned)s1 * PRB);
+      const lds_f *r2 = (const lds_f *)(uintptr_t)(lo + (unsigned)s2 * PRB);
+      const lds_f *r3 = (const lds_f *)(uintptr_t)(lo + (unsigned)s3 * PRB);
+      const lds_f *r4 = (const lds_f *)(uintptr_t)(lo + (unsigned)s4 * PRB);
+      float X_r2[C + 4], Y_r2[C + 4], X_r1[C + 1], Y_r1[C + 1], X_r3[C + 1], Y_r3[C + 1], X_r4[C], Y_r4[C];
+      constexpr int O_r2 = 2, O_r1 = 0, O_r3 = 1, O_r4 = 0, O_r0 = 0;
+#define LDP(r, dj) (*(const lds_f2a *)((r) + (dj)))
+      if constexpr (C == 2) {
+#pragma unroll
+        for (int d = -2; d < C + 2; d += 2) {
+          const f2 a = LDP(r2, d), b = LDP(r2 + YO, d);
+          X_r2[d + 2] = a.x, X_r2[d + 3] = a.y, Y_r2[d + 2] = b.x, Y_r2[d + 3] = b.y;
+        }
+        const f2 a1 = LDP(r1, 0), b1 = LDP(r1 + YO, 0), a3 = LDP(r3, 0), b3 = LDP(r3 + YO, 0), a4 = LDP(r4, 0), b4 = LDP(r4 + YO, 0);
+        X_r1[0] = a1.x, X_r1[1] = a1.y, X_r1[C] = 0.f, Y_r1[0] = b1.x, Y_r1[1] = b1.y, Y_r1[C] = r1[YO + C];
+        X_r3[0] = r3[-1], X_r3[1] = a3.x, X_r3[2] = a3.y, Y_r3[0] = 0.f, Y_r3[1] = b3.x, Y_r3[2] = b3.y;
+        X_r4[0] = a4.x, X_r4[1] = a4.y, Y_r4[0] = b4.x, Y_r4[1] = b4.y;
+      } else {
+#pragma unroll
+        for (int d = -2; d < C + 2; ++d) X_r2[d + 2] = (d == -2) ? 0.f : r2[d], Y_r2[d + 2] = (d == -2) ? 0.f : r2[YO + d];
+#pragma unroll
+        for (int d = 0; d <= C; ++d) X_r1[d] = (d < C) ? r1[d] : 0.f, Y_r1[d] = r1[YO + d];
+#pragma unroll
+        for (int d = -1; d < C; ++d) X_r3[d + 1] = r3[d], Y_r3[d + 1] = (d >= 0) ? r3[YO + d] : 0.f;
+#pragma unroll
+        for (int d = 0; d < C; ++d) X_r4[d] = r4[d], Y_r4[d] = r4[YO + d];
+      }
+#define XY(r, dj) f2{X_##r[(dj) + O_##r], Y_##r[(dj) + O_##r]}
+      const bool rok = (i >= 2) && (i <= n - 2);
+      const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
+      float oxv[C], oyv[C];
+      f2 fEn[C], fNn[C], difv[C];
+      f2 fSw = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < C; ++e) {
+        const int j = j0 + e;
+        const lmask mC = lanes_if((unsigned)(j - 2) <= (unsigned)(m - 4));
+        const lmask mCN = lanes_if((unsigned)(j - 1) <= (unsigned)(m - 4));
+        const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
+        if (t == 0) {
+          const lds_f *r0p = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
+          float X_r0[C], Y_r0[C];
+          if constexpr (C == 2) {
+            const f2 a0 = LDP(r0p, 0), b0 = LDP(r0p + YO, 0);
+            X_r0[0] = a0.x, X_r0[1] = a0.y, Y_r0[0] = b0.x, Y_r0[1] = b0.y;
+          } else {
+#pragma unroll
+            for (int d = 0; d < C; ++d) X_r0[d] = r0p[d], Y_r0[d] = r0p[YO + d];
+          }
+          const bool rokW = (i - 1 >= 2) && (i - 1 <= n - 2);
+          const f2 uo = 0.5f * (f2{cw.x, cs.x} + f2{cc.x, cc.x});
+          fE2[e] = uo * quick_face2(XY(r0, e), cw, cc, ce, uo, rokW ? mC : 0, rok ? mC : 0);
+        }
+        const f2 ue = 0.5f * (f2{ce.x, X_r3[e - 1 + O_r3]} + f2{cc.x, ce.x});
+        fEn[e] = ue * quick_face2(cw, cc, ce, XY(r4, e), ue, rok ? mC : 0, rokE ? mC : 0);
+        if (e == 0) {
+          const f2 vs = 0.5f * (f2{cc.y, cs.y} + f2{cw.y, cc.y});
+          fSw = vs * (0.5f * (cs + cc));
+        }
+        const f2 vn = 0.5f * (f2{cn.y, cc.y} + f2{Y_r1[e + 1], cn.y});
+        fNn[e] = vn * quick_face2(cs, cc, cn, XY(r2, e + 2), vn, rok ? mC : 0, rok ? mCN : 0);
+        difv[e] = ce + cn - 4.f * cc + cw + cs;  // VectorField.pde:198-200
+      }
+#undef XY
+      fSw.x = lane_prev_keep(fSw.x, fNn[C - 1].x);
+      fSw.y = lane_prev_keep(fSw.y, fNn[C - 1].y);
+      f2 basev[C];
+      {
+        wait_vm_le(uni(issued - tag_b));  // base row i: copied at the end of iteration i-1 or by the prologue
+        const lds_f *bb = (const lds_f *)(uintptr_t)(bslot + (unsigned)(2 * (i & 1)) * PRB + 4u * (unsigned)(j0 + 1));
+        if constexpr (C == 2) {
+          const f2 ab = LDP(bb, 0), bb2 = LDP(bb + PR, 0);
+          basev[0] = f2{ab.x, bb2.x}, basev[1] = f2{ab.y, bb2.y};
+        } else {
+#pragma unroll
+          for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
+        }
+      }
+      tag_b = tag_bn;
+#pragma unroll
+      for (int e = 0; e < C; ++e) {
+        const f2 fW = fE2[e], fS = (e == 0) ? fSw : fNn[e > 0 ? e - 1 : 0];
+        const f2 adv = ((fW - fEn[e]) + (fS - fNn[e]));
+        const f2 o = (adv + nu * difv[e]) * dt + basev[e];  // VectorField.pde:174-175
+        oxv[e] = o.x;
+        oyv[e] = o.y;
+        fE2[e] = fEn[e];
+      }
+      {
+        const unsigned ob = 4u * (unsigned)(i * m + j0);
+        const unsigned ln_ = lane_fresh();
+        const bool first = (ln_ == 0u), last = (ln_ == (unsigned)(lanes_on - 1));
+        if (first || last) {
+          const unsigned gb = 4u * (unsigned)(i * m + (first ? 0 : m - 1));
+          st1b(dx, gb, first ? oxv[0] : oxv[C - 1]);
+          st1b(dy, gb, first ? oyv[0] : 0.f);
+        }
+        if (first) oyv[0] = 0.f;
+        if (ln_ < (unsigned)lanes_on) {
+          __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
+          __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
+        }
+        issued += ST;
+      }
+      asm volatile("" ::: "memory");
+      if (t == 0) ADVF_STAGE()  // row i+4 replaces row i-2, whose last reader was this row's west face
+      // ---- the projection of row i+3 (the stencils of the next iteration read up to it); p of row i+4 on its way ----
+      if (i + 3 <= p_hi) {
+        wait_vm_le(uni(issued - tag_p));
+        project_row(i + 3, s5, i + 3 <= i_last, pslot);
+        if (i + 4 <= p_hi) {
+          ADVF_ISSUE(i + 4)
+          tag_p = issued;
+        }
+      }
+      asm volatile("" ::: "memory");
+      s0 = s1;
+    }
+#undef ADVF_STAGE
+#undef ADVF_BASE
+#undef ADVF_ISSUE
+#undef LDP
+  }
+  __syncthreads();
+}

@@ -738,6 +738,8 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
   __syncthreads();
 }
 
+#include "bdim_v2_advfuse.h"
+
 // BDIM.updateUP lines 118-120 restricted to the cells where it is not the identity:
 // del != 1 or del1 != 0 (|d| < eps, plus the solid interior).  Everywhere else
 // u = 1*F - ub*0 + 0*g == F.  Every band cell must see the un-forced F of its neighbours, as the reference's
@@ -3199,7 +3201,7 @@ template <int C, int TAG = 0>
 __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e, float *vx, float *vy,
                                  const float *pin, float *pout,
                                  float *shift_io, const float *ox, const float *oy, float *ax, float *ay, double *sm,
-                                 float *linf_out, ProfT &pf, float *lds, bool hard = false) {
+                                 float *linf_out, ProfT &pf, float *lds, bool hard = false, bool skip_tail = false) {
   const size_t eo = e * (size_t)P.Ns;
   Lv L0 = make_level(P, e, 0);
   L0.x = pout;
@@ -3210,7 +3212,9 @@ __device__ inline int project_v2(const bool HEUN, const StepParams &P, size_t e,
   float psum = xsum;
   if (P.exact_sums) psum = seq_sum(pout, P.n, P.m, sm);  // Field.sum in the reference's order
   const float shift = uni(-1 * psum / (float)((P.n - 2) * (P.m - 2)));  // VectorField.pde:136
-  project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay, uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u));
+  // (skip_tail: the caller's next advection applies the tail to the rows it stages -- advdif_v3f)
+  if (!skip_tail)
+    project_tail_v2(HEUN, P, lds, pout, shift, vx, vy, ox, oy, ax, ay, uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u));
   *shift_io = shift;
   pf.mark(PF_PROJECT);
   return iters;
@@ -3261,7 +3265,7 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
   const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
   const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
   float *Ax = uni(G(P.ux) + eo), *Ay = uni(G(P.uy) + eo), *Bx = uni(G(P.usx) + eo), *By = uni(G(P.usy) + eo),
-        *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo);
+        *Cx = uni(G(P.fx) + eo), *Cy = uni(G(P.fy) + eo), *Qx = uni(G(P.qx) + eo), *Qy = uni(G(P.qy) + eo);
   float *p0 = uni(G(P.p) + eo), *p1 = uni(G(P.d) + eo);  // pressure ping-pong: p0 -> p1 (predictor) -> p0 (corrector)
   float l0, l1;
   float shift = uni(*pshift);
@@ -3277,6 +3281,9 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
   // the barrier-free row pipelines where they apply (adv_ns = ring depth chosen by the host; dbg bit 10 forces the tiled form), else the tiled form
   const int adv3_ns = uni(P.adv_ns);
   const bool adv3_ok = adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024);
+  // the predictor's projection tail inside the corrector's advection (advdif_v3f): the projected predictor field is then
+  // Q, not B
+  const bool fuse = !AFC_DIAG && C <= 2 && adv3_ok && uni(P.fuse_tail) != 0 && uni(P.bc_fold) != 0 && advf_shape_ok(uni(P.n), uni(P.m), C);
 #pragma nounroll
   for (int half = 0; half < 2; ++half) {
     const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
@@ -3284,7 +3291,9 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
     const float *pin = uni(half ? p1 : p0);
     float *pout = uni(half ? p0 : p1);
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
-    if (adv3_ok)
+    if (fuse && half) {
+      if constexpr (C <= 2) advdif_v3f<C>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
+    } else if (adv3_ok)
       advdif_v3<(C > 2 ? 2 : C), C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);  // TAG = C: one instance per kernel instantiation
     else
       advdif_v2<C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);
@@ -3302,8 +3311,8 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
 #if AFC_DIAG
     if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
 #endif
-    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Bx, By, Ax, Ay, sm, &l, pf, lds,
-                                 first_after_action && half == 0);
+    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, fuse ? Qx : Bx, fuse ? Qy : By, Ax, Ay, sm, &l, pf,
+                                 lds, first_after_action && half == 0, fuse && half == 0);
     if (pf.stop >= 3 && pf.stop <= 6) return;
 #if AFC_DIAG
     if (pf.stop) pf.stop += 8 * half;

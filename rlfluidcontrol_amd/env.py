@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
     "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases", "afc_format_float_java", "afc_get_cfl",
     "afc_get_window_complete", "afc_get_mg_histogram", "afc_measure_copy_rate", "afc_op_project",
-    "afc_placement_info",
+    "afc_placement_info", "afc_fused_tail",
 ]
 
 
@@ -40,7 +40,7 @@ class AfcConfig(C.Structure):
         ("init_time", C.c_float), ("end_time", C.c_float), ("num_envs", C.c_int32),
         ("device", C.c_int32), ("mg_max_iters", C.c_int32), ("carry_quirk", C.c_int32),
         ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("impl", C.c_int32), ("stagger_us", C.c_int32), ("reserved", C.c_int32 * 1),
-        ("gs_mode", C.c_int32), ("reserved2", C.c_int32 * 2),
+        ("gs_mode", C.c_int32), ("fuse_tail", C.c_int32), ("reserved2", C.c_int32 * 1),
     ]
 
 
@@ -103,6 +103,7 @@ def load_library():
             raise
     try:  # round 5
         L.afc_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.afc_fused_tail.argtypes = [vp]
     except AttributeError:
         if not os.environ.get("AFC_ENV_LIB"):
             raise
@@ -302,6 +303,15 @@ class AFCEnv:
         self._ck(self._L.afc_placement_info(self._h, C.byref(t), C.byref(b), C.byref(m)), "afc_placement_info")
         return {"trials": int(t.value), "best_GBs": round(float(b.value), 1), "median_GBs": round(float(m.value), 1),
                 "hit": bool(t.value > 1 and b.value >= 1.035 * m.value)}
+
+    def fused_tail(self):
+        """True if the step kernels run the predictor's projection tail inside the corrector's advection (afc_config.fuse_tail)"""
+        if not hasattr(self._L, "afc_fused_tail"):
+            return None
+        r = self._L.afc_fused_tail(self._h)
+        if r < 0:
+            self._ck(r, "afc_fused_tail")
+        return bool(r)
 
     def diverged(self):
         out = np.empty(self.num_envs, np.uint8)

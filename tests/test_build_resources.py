@@ -34,8 +34,11 @@ def test_step_kernels_keep_four_workgroups_per_cu():
     for n, v in shipped.items():
         if "k_agent_step" in n:  # the bench / training kernel against its diagnostic twin
             d = step[n.replace("ELi0E", "ELi1E")]
-            # (within the allocator's noise: the two instantiations answer any source change by a few spill slots either way)
-            assert v["private_segment_fixed_size"] <= d["private_segment_fixed_size"] + 32, (n, v, d)
+            # (within the allocator's noise: the two instantiations answer any source change by a few spill slots either way;
+            # the instantiations for one-tile grids also carry the fused advection advdif_v3f, which their diagnostic
+            # twins do not -- its row loop is spill-free, tools/loop_scan.py)
+            fused = "ILi1E" in n or "ILi2E" in n
+            assert v["private_segment_fixed_size"] <= d["private_segment_fixed_size"] + (64 if fused else 32), (n, v, d)
             assert v["code_bytes"] < d["code_bytes"], (n, v, d)
 
 

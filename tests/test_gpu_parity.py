@@ -182,8 +182,8 @@ def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re, impl):
     g.close()
 
 
-def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0, impl=2):
-    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact, impl=impl)
+def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0, impl=2, fuse_tail=0):
+    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact, impl=impl, fuse_tail=fuse_tail)
     o = oracle_mod.Oracle(resolution=res, Re=Re)
     if init is not None:
         g.set_reset_state(init["u"], init["v"], init["p"])
@@ -267,6 +267,52 @@ def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init, 
     assert np.array_equal(g.vorticity(), o.vorticity())
     assert np.array_equal(g.probes(32)[0], o.probes(32))
     _, rg = g.solver_stats()
+    g.close()
+
+
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100)])
+def test_fused_projection_tail_is_bit_exact(envmod, oracle_mod, res, Re):
+    """afc_config.fuse_tail = 1: the predictor's projection tail (VectorField.pde:136-140) and the row part of setBC run
+    inside the corrector's advection pass (advdif_v3f) -- in parity mode every float still equals the oracle's; and with
+    the default sums the fused and the two-pass form agree bit for bit with each other (from a cold start: the first
+    steps take several V-cycles, saturated and mixed actions, several envs)."""
+    acts = [(0, 0)] * 3 + [(5.0, -5.0)] * 5 + [(-2.5, 1.0)] * 4 + [(0, 0)] * 4
+    g, o, out = _run_pair(envmod, oracle_mod, res, Re, len(acts), acts, exact=1, fuse_tail=1)
+    assert g.fused_tail() is True
+    for k, (fg, fo, itg, ito) in enumerate(out):
+        assert tuple(itg[0]) == tuple(ito), k
+        assert np.array_equal(fg[0], fo), (k, fg[0], fo)
+    ug, vg, pg = g.get_state()
+    uo, vo, po = o.get_state()
+    assert np.array_equal(ug, uo) and np.array_equal(vg, vo) and np.array_equal(pg, po)
+    g.close()
+    E = 5
+    ga = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re, fuse_tail=1)
+    gb = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=Re, fuse_tail=-1)
+    assert ga.fused_tail() is True and gb.fused_tail() is False
+    rng = np.random.default_rng(23)
+    a = (5 * rng.uniform(-1, 1, size=(10, E, 2))).astype(np.float32)
+    for k in range(10):
+        assert np.array_equal(ga.update2(a[k]), gb.update2(a[k])), k
+    for e in range(E):
+        for x, y in zip(ga.get_state(e), gb.get_state(e)):
+            assert np.array_equal(x, y), e
+    ga.close()
+    gb.close()
+
+
+def test_fused_projection_tail_is_chosen_by_occupancy(envmod):
+    """default (fuse_tail = 0): fused where a launch puts more than two envs on a CU and the grid is one column tile wide"""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    g = envmod.AFCEnv(num_envs=4, resolution=8, reynolds=100)
+    assert g.fused_tail() is False
+    g.close()
+    g = envmod.AFCEnv(num_envs=2 * cus + 1, resolution=8, reynolds=100)
+    assert g.fused_tail() is True
+    g.close()
+    g = envmod.AFCEnv(num_envs=2, resolution=24, reynolds=500, fuse_tail=1)  # two column tiles: not available
+    assert g.fused_tail() is False
     g.close()
 
 
