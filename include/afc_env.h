@@ -108,10 +108,12 @@ typedef struct afc_config {
                            of levels> in the environment selects others, 0 none: same bits).  No diagnostics:
                            afc_create refuses it together with stagger_us != 0 or reserved[0] != 0, afc_profile_phases
                            refuses to enable stamps; afc_op_mg_solve / afc_op_project run the red-black smoother too */
-  int32_t fuse_tail;    /* the predictor's projection tail (VectorField.pde:136-140) inside the corrector's advection pass
-                           (advdif_v3f: the projected field is never re-read from memory; same bits either way):
-                           0 (default) = where it is faster -- one-tile grids (<= 128 interior columns) in launches of more
-                           than two envs per CU; 1 = wherever the grid allows it; -1 = never */
+  int32_t fuse_tail;    /* the tail of u.project (VectorField.pde:136-140: u -= c grad p, setBC) -- and, for the corrector, the
+                           Heun average of BDIM.pde:95-96 -- inside the advection pass that follows it (advdif_v3f: the
+                           projected field is not re-read from memory; inside a launch of several sim-steps the corrector's
+                           tail runs in the next sim-step's predictor pass; same bits either way):
+                           0 (default) = where it is faster -- one-tile grids (<= 128 interior columns) in launches of at
+                           least one env per CU; 1 = wherever the grid allows it; -1 = never */
   int32_t reserved2[1];
 } afc_config;
 
@@ -231,8 +233,8 @@ int afc_measure_copy_rate(int device, uint64_t bytes, int reps, float *gb_per_s)
  * the median one.  A kept candidate less than 3.5 % above the median means the search ended without a fast placement. */
 int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *median_gbs);
 
-/* 1 if this env's step kernels run the corrector's advection with the predictor's projection tail inside it
- * (afc_config.fuse_tail, advdif_v3f), 0 if the two are separate passes; negative on error */
+/* 1 if this env's step kernels run the projection tails inside the advection passes that follow them
+ * (afc_config.fuse_tail, advdif_v3f), 0 if they are separate passes; negative on error */
 int afc_fused_tail(const afc_env *env);
 
 #ifdef __cplusplus

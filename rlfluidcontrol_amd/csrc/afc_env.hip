@@ -431,7 +431,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     if (P.impl != 0 && (one_tile || two_tiles) && a3 <= fl && rows_per_wave >= 8) P.adv_ns = afc::prod::kAdvNS;
   }
 
-  // advdif_v3f (the predictor's projection tail inside the corrector's advection): one more ring row per wave.  The
+  // advdif_v3f (a projection tail inside the advection pass that follows it): one more ring row per wave.  The
   // diagnostic instantiation never runs it and keeps the smaller region (its static part is 2 KB larger); every other
   // "does it fit" above and below is answered for the smaller region.
   env->lds_bytes_step = env->lds_bytes;
@@ -439,21 +439,25 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   {
     const int m_ = sf.m - 2, cplv = (m_ + 63) / 64;
     const size_t af = cplv <= 2 ? (size_t)afc::prod::advf_lds_floats(cplv) * sizeof(float) : 0;
-    // Measured on the same memory (tools/ab_inproc.py --share-slab): -1.1 % per launch with four workgroups per CU
-    // (1024 envs), -0.1 % with two, +1.7 % with one -- a wave alone on its SIMD has nobody to hide the projection's
-    // LDS round trips behind.  So by default: fused where a launch puts more than two workgroups on a CU
-    // (afc_config.fuse_tail: 1 = wherever the shape allows, -1 = never).
+    // Measured on the same memory (tools/ab_inproc.py --share-slab, 256x128, per launch of 16 sim-steps; first figure:
+    // only the predictor's tail fused, second: the corrector's too):
+    //   1024 envs -1.3 / -4.3 %   768: -1.4 / -6.2 %   512: 0.0 / -4.1 %   256: +1.5 / -0.8 %   64: +2.6 / +2.6 %   1: +3.0 / +4.3 %
+    // -- a wave alone on its SIMD has nobody to hide the projection's LDS round trips behind.  So by default: both, in
+    // launches of at least one env per CU (afc_config.fuse_tail: 1 = wherever the shape allows, -1 = never).
     int cus = 256;
     {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    bool want = cfg->fuse_tail > 0 || (cfg->fuse_tail == 0 && (long long)env->E > 2ll * cus);
+    int level = (cfg->fuse_tail > 0 || (cfg->fuse_tail == 0 && (long long)env->E >= (long long)cus)) ? 2 : 0;
 #if AFC_DEVHOOKS
-    if (const char *ft = getenv("AFC_FUSE_TAIL")) want = atoi(ft) != 0;  // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1
+    // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1 lib.so:AFC_FUSE_TAIL=2 (1: only the predictor's tail)
+    if (const char *ft = getenv("AFC_FUSE_TAIL")) level = atoi(ft);
 #endif
-    if (P.impl != 0 && P.adv_ns && cplv <= 2 && afc::prod::advf_shape_ok(sf.n, sf.m, cplv) && af + 512 <= 40960 && want) {
-      P.fuse_tail = 1;
+    if (P.impl != 0 && P.adv_ns && cplv <= 2 && afc::prod::advf_shape_ok(sf.n, sf.m, cplv) && af + 512 <= 40960 && level > 0) {
+      // 1: the predictor's tail in the corrector's advection; 2: also the corrector's tail + Heun average in the next
+      // sim-step's predictor advection, inside a launch of several sim-steps
+      P.fuse_tail = level > 1 ? 2 : 1;
       if (af > env->lds_bytes_step) env->lds_bytes_step = af;
     }
   }

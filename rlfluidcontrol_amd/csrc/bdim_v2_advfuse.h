@@ -34,12 +34,17 @@ __device__ __host__ __forceinline__ bool advf_shape_ok(int n, int m, int C) {
   return (C == 1 || C == 2) && (m - 2) <= 64 * C && ((m - 2) % C) == 0 && ((n - 2) & 3) == 0 && (n - 2) >= 4 * 8;
 }
 
-template <int C>
+// HEUN = false: the corrector's advection (BDIM.update2) on the projected predictor field: raw = F of the predictor,
+//   b = the base field u0 (row copies, one row ahead), q = where the projected field goes (`us` of the Heun average).
+// HEUN = true: the NEXT sim-step's predictor advection (BDIM.update) on u = (project(F2) + us) / 2 (BDIM.pde:95-96):
+//   raw = F of the corrector, b = us (its rows are averaged into the projected row as it is formed), q = u itself --
+//   the advection's base is its own source, taken from the ring.  The sim-step before left out its projection tail.
+template <int C, bool HEUN>
 __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__restrict__ sx, const float *__restrict__ sy,
                                         const float *__restrict__ bx, const float *__restrict__ by,
                                         float *__restrict__ dx, float *__restrict__ dy, float *lds,
-                                        const float *__restrict__ pp, const float shift, float *__restrict__ qx,
-                                        float *__restrict__ qy) {
+                                        const float *__restrict__ pp, const float shift, float *__restrict__ qx_,
+                                        float *__restrict__ qy_) {
   static_assert(C == 1 || C == 2, "one column tile of 64*C columns");
   constexpr int PR = 64 * C + 4, NS = kAdvfNS;
   constexpr unsigned PRB = PR * 4u;
@@ -150,39 +155,53 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       if (first) vs[0] = 0.f;
       const float wu = first ? un[0] : un[C - 1], wv = first ? vn[0] : 0.f;  // the lane's wall column (lane 0: 0, last lane: m-1)
       const int wi = first ? -1 : C;                                          // ... and its place in the ring row
-      auto put_ring = [&](lds_f *r, const float *xu, const float xw) {
+      // one row of the result: into ring row r (lane position) and -- by the owner -- into row `grow` of the field q.
+      // HEUN: averaged with row `grow` of us (in the base slot of its parity), wall columns and all (BDIM.pde:95-96 after
+      // setBC: project_tail_v2's `(un + b) * 0.5f`, `(0.f + d) * 0.5f` at the walls, and its four redone rows)
+      auto emit = [&](lds_f *r, const int grow, const float *xu, const float xw) {
+        float au[C], av[C], aw = xw, awv = wv;
+#pragma unroll
+        for (int e = 0; e < C; ++e) au[e] = xu[e], av[e] = vs[e];
+        if constexpr (HEUN) {
+          const lds_f *rq = (const lds_f *)(uintptr_t)(bslot + (unsigned)(2 * (grow & 1)) * PRB + 4u * (unsigned)(j0 + 1));
+          float qx[C], qy[C];
+          if constexpr (C == 2) {
+            const f2 a = *(const lds_f2a *)rq, b = *(const lds_f2a *)(rq + PR);
+            qx[0] = a.x, qx[1] = a.y, qy[0] = b.x, qy[1] = b.y;
+          } else {
+            qx[0] = rq[0], qy[0] = rq[PR];
+          }
+#pragma unroll
+          for (int e = 0; e < C; ++e) au[e] = (xu[e] + qx[e]) * 0.5f, av[e] = (vs[e] + qy[e]) * 0.5f;
+          if (first || last) aw = (xw + rq[wi]) * 0.5f, awv = (wv + rq[PR + wi]) * 0.5f;
+        }
         if (on) {
 #pragma unroll
-          for (int e = 0; e < C; ++e) r[e] = xu[e], r[YO + e] = vs[e];
-          if (first || last) r[wi] = xw, r[YO + wi] = wv;
+          for (int e = 0; e < C; ++e) r[e] = au[e], r[YO + e] = av[e];
+          if (first || last) r[wi] = aw, r[YO + wi] = awv;
         }
-      };
-      auto put_field = [&](const int row, const float *xu, const float xw) {
-        if (first || last) {
-          const unsigned gb = 4u * (unsigned)(row * m + (first ? 0 : m - 1));
-          st1b(qx, gb, xw);
-          st1b(qy, gb, wv);
+        if (own) {
+          if (first || last) {
+            const unsigned gb = 4u * (unsigned)(grow * m + (first ? 0 : m - 1));
+            st1b(qx_, gb, aw);
+            st1b(qy_, gb, awv);
+          }
+          if (on) {
+            const unsigned ob = 4u * (unsigned)(grow * m + j0);
+            __builtin_memcpy((char *)qx_ + ob, au, sizeof(float) * C);
+            __builtin_memcpy((char *)qy_ + ob, av, sizeof(float) * C);
+          }
+          issued += ST;
         }
-        if (on) {
-          const unsigned ob = 4u * (unsigned)(row * m + j0);
-          __builtin_memcpy((char *)qx + ob, xu, sizeof(float) * C);
-          __builtin_memcpy((char *)qy + ob, vs, sizeof(float) * C);
-        }
-        issued += ST;
       };
       if (g == 1) {  // setBC: row 0 = row 1, then u.x[1][.] = 1 (Field.pde:207-212)
         float one[C];
 #pragma unroll
         for (int e = 0; e < C; ++e) one[e] = 1.f;
-        put_ring((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s == 0 ? NS - 1 : s - 1) * PRB), un, wu);
-        put_ring(ru, one, 1.f);
-        if (own) {
-          put_field(0, un, wu);
-          put_field(1, one, 1.f);
-        }
+        emit((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s == 0 ? NS - 1 : s - 1) * PRB), 0, un, wu);
+        emit(ru, 1, one, 1.f);
       } else {
-        put_ring(ru, un, wu);
-        if (own) put_field(g, un, wu);
+        emit(ru, g, un, wu);
       }
       if (g == n_) {  // row n-1 = row n-2, u.x with the flux correction 1 - mean (Field.pde:213-216, 302-318: in this order)
         float sum = 0;
@@ -196,48 +215,68 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
         float uc[C];
 #pragma unroll
         for (int e = 0; e < C; ++e) uc[e] = un[e] + corr;
-        put_ring((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s + 1 == NS ? 0 : s + 1) * PRB), uc, wu);
-        if (own) put_field(n - 1, uc, wu);
+        emit((lds_f *)(uintptr_t)(ring + 4u * (unsigned)(j0 + 1) + (unsigned)(s + 1 == NS ? 0 : s + 1) * PRB), n - 1, uc, wu);
       }
     };
-    // ---- prologue: raw rows i_first-2 .. i_first+2 staged and projected; then rows i_first+3, i_first+4, base row
-    // i_first and p of row i_first+3 on their way.  The up to six rows of p the five projections need (g0-1 .. i_first+2)
-    // arrive TOGETHER, in the six row slots that are still idle -- ring slot 5 of both components and the four base
-    // slots -- so that the prologue is one round trip plus one per row that crosses a body (the single pair of
-    // coefficient slots), not one per row. ----
+    // ---- prologue: raw rows i_first-2 .. i_first+2 staged and projected; then row i_first+3, base row i_first and p
+    // of row i_first+3 on their way.
+    // HEUN = false: the up to six rows of p the five projections need (g0-1 .. i_first+2) arrive TOGETHER, in the six
+    // row slots that are still idle -- ring slot 5 of both components and the four base slots -- so that the prologue
+    // is one round trip plus one per row that crosses a body (the single pair of coefficient slots), not one per row.
+    // HEUN = true: the base slots carry the rows of us; one round trip per row. ----
+    const int q_hi = (p_hi == n_) ? n - 1 : p_hi;  // HEUN: last row of us this wave needs (the last wave: row n-1 too)
+    int tag_q = 0;
     for (int q = 0; q < 5; ++q) ADVF_STAGE()
-    {
-      const unsigned ln_ = lane_fresh();
-      for (int g = g0 - 1; g <= i_first + 2; ++g) {
-        const int k = g - (i_first - 3);  // 0 .. 5
-        const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
-        if (ln_ < (unsigned)LQ) lds_dma16(ppc, 4u * (unsigned)(g * m) + 16u * ln_, slot);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int k0 = (g0 - 1) - (i_first - 3);
-      const unsigned slot0 = (k0 < 2) ? ring + (unsigned)(5 + k0 * NS) * PRB : bslot + (unsigned)(k0 - 2) * PRB;
-      const lds_f *rp = (const lds_f *)(uintptr_t)(slot0 + 4u * (unsigned)(2 + C * (int)ln_));
-#pragma unroll
-      for (int e = 0; e < C; ++e) pw[e] = rp[e];
-    }
-    for (int g = g0; g <= i_first + 2; ++g) {
-      const int k = g - (i_first - 3);
-      const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
-      if (g >= sp0 && g <= sp1) {
+    if constexpr (!HEUN) {
+      {
         const unsigned ln_ = lane_fresh();
-        const unsigned so_ = 4u * (unsigned)(g * m) + 16u * ln_;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (ln_ < (unsigned)LQ) {
-          lds_dma16(pcx, so_, pslot + PRB);
-          lds_dma16(pcy, so_, pslot + 2u * PRB);
+        for (int g = g0 - 1; g <= i_first + 2; ++g) {
+          const int k = g - (i_first - 3);  // 0 .. 5
+          const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
+          if (ln_ < (unsigned)LQ) lds_dma16(ppc, 4u * (unsigned)(g * m) + 16u * ln_, slot);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int k0 = (g0 - 1) - (i_first - 3);
+        const unsigned slot0 = (k0 < 2) ? ring + (unsigned)(5 + k0 * NS) * PRB : bslot + (unsigned)(k0 - 2) * PRB;
+        const lds_f *rp = (const lds_f *)(uintptr_t)(slot0 + 4u * (unsigned)(2 + C * (int)ln_));
+#pragma unroll
+        for (int e = 0; e < C; ++e) pw[e] = rp[e];
       }
-      project_row(g, g - (i_first - 2), g >= i_first, slot);
+      for (int g = g0; g <= i_first + 2; ++g) {
+        const int k = g - (i_first - 3);
+        const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
+        if (g >= sp0 && g <= sp1) {
+          const unsigned ln_ = lane_fresh();
+          const unsigned so_ = 4u * (unsigned)(g * m) + 16u * ln_;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (ln_ < (unsigned)LQ) {
+            lds_dma16(pcx, so_, pslot + PRB);
+            lds_dma16(pcy, so_, pslot + 2u * PRB);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        project_row(g, g - (i_first - 2), g >= i_first, slot);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the readers of the borrowed slots are done
+    } else {
+      ADVF_ISSUE(g0 - 1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      {
+        const lds_f *rp = (const lds_f *)(uintptr_t)(pslot + 4u * (unsigned)(2 + C * (int)lane_fresh()));
+#pragma unroll
+        for (int e = 0; e < C; ++e) pw[e] = rp[e];
+      }
+      for (int g = g0; g <= i_first + 2; ++g) {
+        ADVF_ISSUE(g)
+        if (g == 1) ADVF_BASE(0)
+        ADVF_BASE(g)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        project_row(g, g - (i_first - 2), g >= i_first, pslot);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next row's copy of us goes where the row before this one's was read)
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the readers of the borrowed slots are done
     ADVF_STAGE()  // row i_first+3
-    ADVF_BASE(i_first)
+    ADVF_BASE(HEUN ? i_first + 3 : i_first)
     int tag_b = issued;  // base row i
     ADVF_ISSUE(i_first + 3)
     int tag_p = issued;
@@ -246,9 +285,16 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
     for (int i = i_first; i <= i_last; ++i) {
       const int t = i - i_first;
       int tag_bn = tag_b;
-      if (i < i_last) {
-        ADVF_BASE(i + 1)
-        tag_bn = issued;
+      if constexpr (!HEUN) {
+        if (i < i_last) {
+          ADVF_BASE(i + 1)
+          tag_bn = issued;
+        }
+      } else {
+        if (i + 4 <= q_hi) {  // us of row i+4 (read when that row is projected, at the end of the next iteration)
+          ADVF_BASE(i + 4)
+          tag_q = issued;
+        }
       }
       if (t > 0) ADVF_STAGE()  // raw row i+4 replaces row i-2
       const int j0 = 1 + C * (int)lane_fresh();
@@ -287,7 +333,7 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       const bool rok = (i >= 2) && (i <= n - 2);
       const bool rokE = (i + 1 >= 2) && (i + 1 <= n - 2);
       float oxv[C], oyv[C];
-      f2 fEn[C], fNn[C], difv[C];
+      f2 fEn[C], fNn[C], difv[C], ccv[C];
       f2 fSw = {0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < C; ++e) {
@@ -295,6 +341,7 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
         const lmask mC = lanes_if((unsigned)(j - 2) <= (unsigned)(m - 4));
         const lmask mCN = lanes_if((unsigned)(j - 1) <= (unsigned)(m - 4));
         const f2 cc = XY(r2, e), ce = XY(r3, e), cw = XY(r1, e), cn = XY(r2, e + 1), cs = XY(r2, e - 1);
+        ccv[e] = cc;
         if (t == 0) {
           const lds_f *r0p = (const lds_f *)(uintptr_t)(lo + (unsigned)s0 * PRB);
           float X_r0[C], Y_r0[C];
@@ -323,8 +370,8 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       fSw.x = lane_prev_keep(fSw.x, fNn[C - 1].x);
       fSw.y = lane_prev_keep(fSw.y, fNn[C - 1].y);
       f2 basev[C];
-      {
-        wait_vm_le(uni(issued - tag_b));  // base row i: copied at the end of iteration i-1 or by the prologue
+      if constexpr (!HEUN) {
+        wait_vm_le(uni(issued - tag_b));  // base row i: copied in iteration i-1 or by the prologue
         const lds_f *bb = (const lds_f *)(uintptr_t)(bslot + (unsigned)(2 * (i & 1)) * PRB + 4u * (unsigned)(j0 + 1));
         if constexpr (C == 2) {
           const f2 ab = LDP(bb, 0), bb2 = LDP(bb + PR, 0);
@@ -333,6 +380,9 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
 #pragma unroll
           for (int e = 0; e < C; ++e) basev[e] = f2{bb[e], bb[PR + e]};
         }
+      } else {  // BDIM.update: u0 = u
+#pragma unroll
+        for (int e = 0; e < C; ++e) basev[e] = ccv[e];
       }
       tag_b = tag_bn;
 #pragma unroll
@@ -364,7 +414,8 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       if (t == 0) ADVF_STAGE()  // row i+4 replaces row i-2, whose last reader was this row's west face
       // ---- the projection of row i+3 (the stencils of the next iteration read up to it); p of row i+4 on its way ----
       if (i + 3 <= p_hi) {
-        wait_vm_le(uni(issued - tag_p));
+        // (HEUN: us of row i+3 was copied an iteration before its p; the last wave's row n-1 of us only in this one)
+        wait_vm_le(uni(issued - ((HEUN && i + 3 == n_ && tag_q > tag_p) ? tag_q : tag_p)));
         project_row(i + 3, s5, i + 3 <= i_last, pslot);
         if (i + 4 <= p_hi) {
           ADVF_ISSUE(i + 4)

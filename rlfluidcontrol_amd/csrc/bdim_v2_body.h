@@ -3260,7 +3260,12 @@ __device__ __forceinline__ void eval_force_wave(const StepParams &P, const float
 // k_agent_step and allocated without their register cap)
 template <int C>
 __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float xi1_m, float xi2_m, float *pshift, double *sm,
-                                   ShBcast *sh, float *lds, const bool first_after_action = false) {
+                                   ShBcast *sh, float *lds, const bool first_after_action = false, const bool heun_in = false,
+                                   const bool defer_out = false) {
+  // heun_in: the sim-step before this one left out the tail of its corrector's projection and the Heun average
+  // (BDIM.pde:95-96): u in memory is stale, this step's predictor advection forms it from F2, p and us as it goes
+  // (advdif_v3f<C, true>).  defer_out: this step leaves them out in turn -- the caller promises that another sim-step
+  // of the same launch follows (heun_fusable() says whether this env's kernels can do either).
   const size_t eo = e * (size_t)P.Ns;
   const float dphi1 = uni((2 * xi1_m * P.dt) / (P.dR * P.D));  // AFCCylinder.pde:48-49
   const float dphi2 = uni((2 * xi2_m * P.dt) / (P.dR * P.D));
@@ -3292,7 +3297,9 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
     float *pout = uni(half ? p0 : p1);
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (fuse && half) {
-      if constexpr (C <= 2) advdif_v3f<C>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
+      if constexpr (C <= 2) advdif_v3f<C, false>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
+    } else if (fuse && heun_in) {
+      if constexpr (C <= 2) advdif_v3f<C, true>(P, Cx, Cy, Qx, Qy, Bx, By, lds, p0, shift, Ax, Ay);
     } else if (adv3_ok)
       advdif_v3<(C > 2 ? 2 : C), C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);  // TAG = C: one instance per kernel instantiation
     else
@@ -3312,7 +3319,7 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
     if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
 #endif
     const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, fuse ? Qx : Bx, fuse ? Qy : By, Ax, Ay, sm, &l, pf,
-                                 lds, first_after_action && half == 0, fuse && half == 0);
+                                 lds, first_after_action && half == 0, fuse && (half == 0 || defer_out));
     if (pf.stop >= 3 && pf.stop <= 6) return;
 #if AFC_DIAG
     if (pf.stop) pf.stop += 8 * half;
@@ -3343,6 +3350,20 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
   }
   __syncthreads();
   pf.mark(PF_HEUN);
+}
+
+// can this env's step kernels leave the Heun tail of a sim-step to the next one (sim_step_v2's heun_in / defer_out)?
+template <int C>
+__device__ __forceinline__ bool heun_fusable(const StepParams &P) {
+  const int adv3_ns = uni(P.adv_ns);
+  return !AFC_DIAG && C <= 2 && adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024) && uni(P.fuse_tail) > 1 && uni(P.bc_fold) != 0 &&
+         advf_shape_ok(uni(P.n), uni(P.m), C);
+}
+// the tail a sim-step left out, on its own (a launch that ends with one pending: the state in memory must be complete)
+__device__ __forceinline__ void heun_tail_only(const StepParams &P, size_t e, float shift, float *lds) {
+  const size_t eo = e * (size_t)P.Ns;
+  project_tail_v2(true, P, lds, uni(G(P.p) + eo), shift, uni(G(P.fx) + eo), uni(G(P.fy) + eo), uni(G(P.qx) + eo), uni(G(P.qy) + eo),
+                  uni(G(P.ux) + eo), uni(G(P.uy) + eo), true);
 }
 
 #undef AFC_DBG_OF

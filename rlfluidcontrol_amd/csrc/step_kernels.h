@@ -32,11 +32,12 @@ using afc::StepParams;
 // bdim_v2.h): 0 = shipped, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; cfg.gs_mode = 1).
 template <int CPL, int MODE>
 __device__ __forceinline__ void step_dispatch(const StepParams &P, size_t e, float a, float b, float *pshift,
-                                              double *sm, afc::ShBcast *sh, float *lds, bool first_after_action = false) {
+                                              double *sm, afc::ShBcast *sh, float *lds, bool first_after_action = false,
+                                              bool heun_in = false, bool defer_out = false) {
   if constexpr (CPL == 0)
     afc::sim_step(P, e, a, b, sm, sh);
   else
-    afc::AFC_MODE_NS::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds, first_after_action);
+    afc::AFC_MODE_NS::sim_step_v2<CPL>(P, e, a, b, pshift, sm, sh, lds, first_after_action, heun_in, defer_out);
 }
 
 template <int CPL, int MODE>
@@ -121,10 +122,27 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   float pshift = s.p_shift;
   int steps = 0;
   long long dbg_t0 = 0;
+  // A sim-step that is followed by another one in this launch may leave the tail of its corrector's projection and the
+  // Heun average to the next step's advection pass (sim_step_v2: heun_in / defer_out).  Whether another one follows is
+  // known before the step: the loop below ends on the step count, on the time after the step, or on the action window
+  // completing with it (clientCFD.pde:36-47) -- the same expressions, evaluated in advance.  Should the loop end with
+  // a tail pending all the same, the tail runs on its own after it.
+  bool heun_pending = false;
+  bool can_defer = false;
+  if constexpr (CPL >= 1 && CPL <= 2 && !DIAG) can_defer = afc::AFC_MODE_NS::heun_fusable<CPL>(P);
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
     if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
-    step_dispatch<CPL, MODE>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn, AFC_HARD_HINT(steps == 0));  // the action is new in the first step
+    bool defer = false;
+    if (can_defer) {
+      float t_after = s.t;
+      t_after += P.dt / P.resolution;
+      const bool window_ends = (t_after > P.init_time) && (s.callLearn - 1 <= 0);
+      defer = (steps + 1 < max_steps) && (t_after < P.end_time) && !window_ends;
+      defer = afc::AFC_MODE_NS::uni((int)defer) != 0;
+    }
+    step_dispatch<CPL, MODE>(P, e, xi1_m, xi2_m, &pshift, sm, &sh, lds_dyn, AFC_HARD_HINT(steps == 0), heun_pending, defer);  // the action is new in the first step
+    heun_pending = defer;
     ++steps;
     if (threadIdx.x == 0) {
       s.t += P.dt / P.resolution;
@@ -159,6 +177,9 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     }
     __syncthreads();
     if (s_stop) break;
+  }
+  if constexpr (CPL >= 1 && CPL <= 2 && !DIAG) {
+    if (heun_pending) afc::AFC_MODE_NS::heun_tail_only(P, e, pshift, lds_dyn);
   }
   if (DIAG && CPL != 0) afc::gate_release(P, true);
   if (threadIdx.x == 0) {

@@ -302,13 +302,13 @@ def test_fused_projection_tail_is_bit_exact(envmod, oracle_mod, res, Re):
 
 
 def test_fused_projection_tail_is_chosen_by_occupancy(envmod):
-    """default (fuse_tail = 0): fused where a launch puts more than two envs on a CU and the grid is one column tile wide"""
+    """default (fuse_tail = 0): fused where a launch has at least one env per CU and the grid is one column tile wide"""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     g = envmod.AFCEnv(num_envs=4, resolution=8, reynolds=100)
     assert g.fused_tail() is False
     g.close()
-    g = envmod.AFCEnv(num_envs=2 * cus + 1, resolution=8, reynolds=100)
+    g = envmod.AFCEnv(num_envs=cus, resolution=8, reynolds=100)
     assert g.fused_tail() is True
     g.close()
     g = envmod.AFCEnv(num_envs=2, resolution=24, reynolds=500, fuse_tail=1)  # two column tiles: not available

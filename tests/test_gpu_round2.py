@@ -334,6 +334,41 @@ def test_experiment_paths_are_bit_identical_to_the_default(envmod, dbg, what, ex
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), what
 
 
+@pytest.mark.parametrize("res", [8, 16])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_fused_tails_through_launches_of_many_sim_steps(envmod, res, exact):
+    """afc_config.fuse_tail = 1 against -1 through agent steps: inside a launch every sim-step but the last leaves the tail
+    of its corrector's projection and the Heun average (BDIM.pde:95-96) to the next sim-step's predictor advection
+    (advdif_v3f<C, true>), the last one runs it as a pass of its own so that the state in memory is complete.  40 envs
+    with different actions from a cold start (the first launch runs 130+ sim-steps up to init_time = 1 and its first
+    solves take several V-cycles), then action windows of 16: every observation, reward and step count, the multigrid
+    histogram and the final fields are bit-identical; and single sim-step launches (update2) in between keep working."""
+    rng = np.random.default_rng(5)
+    E = 40
+    acts = rng.uniform(-1, 1, (5, E, 2)).astype(np.float32)
+    recs = []
+    for fuse in (1, -1):
+        g = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=100, exact_sums=exact, fuse_tail=fuse)
+        assert g.fused_tail() is (fuse == 1)
+        rec = []
+        for k in range(5):
+            obs, rew, done, ns = g.agent_step(acts[k])
+            rec.append((obs.copy(), rew.copy(), ns.copy()))
+            if k == 2:
+                rec.append((g.update2(5 * acts[k]).copy(), rew.copy(), ns.copy()))
+        st = [g.get_state(e) for e in (0, 7, E - 1)]
+        recs.append((rec, st, g.mg_histogram()))
+        g.close()
+    (ra, sa, ha), (rb, sb, hb) = recs
+    assert ra[0][2][0] > 100 and np.array_equal(ha, hb)
+    for (o1, w1, n1), (o2, w2, n2) in zip(ra, rb):
+        assert np.array_equal(n1, n2) and np.array_equal(o1.view(np.uint32), o2.view(np.uint32))
+        assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+    for x, y in zip(sa, sb):
+        for f1, f2 in zip(x, y):
+            assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+
 def test_shipped_and_diagnostic_instantiations_agree_bit_for_bit(envmod):
     """afc::prod (dbg == 0) and afc::diag (any dbg != 0) are the same code with and without the diagnostics compiled in"""
     for exact in (1, 0):
