@@ -656,9 +656,16 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (!rc) rc = dev_upload(env, &P.fs, fs);
 
   const size_t E = (size_t)env->E;
-  AFC_AS1 float **fields[] = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d, &P.qx, &P.qy};
+  // (qx, qy: the projected predictor field of the fused advection passes -- only envs that run them carry it, so that
+  // the slab of every other env is what it was: the placement search works on the slab's size)
+  std::vector<AFC_AS1 float **> fields = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
+  if (P.fuse_tail) {
+    fields.push_back(&P.qx);
+    fields.push_back(&P.qy);
+  }
+  const size_t nfields = fields.size();
   {
-    // The per-env state lives in ONE allocation (the thirteen fine fields back to back, then the coarse scratch): the
+    // The per-env state lives in ONE allocation (the eleven or thirteen fine fields back to back, then the coarse scratch): the
     // same library ran 7 % apart between env instances whose arrays came from separate hipMalloc calls (same box, same
     // process, launches interleaved: tools/ab_inproc.py) -- where the driver happens to place a dozen 140 MB buffers
     // decides how the streams of a phase fall on the memory channels / translation fragments.
@@ -684,7 +691,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     } else {
       float *slab = nullptr;
       const size_t scz = ((E * sizeof(EnvScalars) + 255) / 256) * 64;  // the per-env scalars, in floats, at the end of the slab
-      const size_t total = kFront + 13 * fsz + csz + scz;
+      const size_t total = kFront + nfields * fsz + csz + scz;
       // development (tools/ab_inproc.py --share-slab): an instance adopts the slab of another instance of the same shape,
       // so that builds are compared on the SAME memory (placements of the fast kind still differ by +-0.5 %)
       // (compiled in with -DAFC_DEVHOOKS=1 only -- tools/build_variant.sh; the shipped library takes no pointers from
@@ -797,10 +804,10 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           setenv("AFC_LAST_SLAB", buf, 1);
         }
 #endif
-        P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + 13 * fsz + csz);
+        P.sc = (AFC_AS1 EnvScalars *)(slab + kFront + nfields * fsz + csz);
         size_t k = 0;
         for (AFC_AS1 float **f : fields) *f = (AFC_AS1 float *)(slab + kFront + (k++) * fsz);
-        P.coarse = (AFC_AS1 float *)(slab + kFront + 13 * fsz);
+        P.coarse = (AFC_AS1 float *)(slab + kFront + nfields * fsz);
       }
     }
   }
