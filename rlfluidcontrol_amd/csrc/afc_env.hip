@@ -438,7 +438,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.fuse_tail = 0;
   {
     const int m_ = sf.m - 2, cplv = (m_ + 63) / 64;
-    const size_t af = cplv <= 2 ? (size_t)afc::prod::advf_lds_floats(cplv) * sizeof(float) : 0;
+    const size_t af = (size_t)afc::prod::advf_lds_floats(cplv > 2 ? 2 : cplv) * sizeof(float);
     // Measured on the same memory (tools/ab_inproc.py --share-slab, 256x128, per launch of 16 sim-steps; first figure:
     // only the predictor's tail fused, second: the corrector's too):
     //   1024 envs -1.3 / -4.3 %   768: -1.4 / -6.2 %   512: 0.0 / -4.1 %   256: +1.5 / -0.8 %   64: +2.6 / +2.6 %   1: +3.0 / +4.3 %
@@ -454,7 +454,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1 lib.so:AFC_FUSE_TAIL=2 (1: only the predictor's tail)
     if (const char *ft = getenv("AFC_FUSE_TAIL")) level = atoi(ft);
 #endif
-    if (P.impl != 0 && P.adv_ns && cplv <= 2 && afc::prod::advf_shape_ok(sf.n, sf.m, cplv) && af + 512 <= 40960 && level > 0) {
+    if (P.impl != 0 && P.adv_ns && cplv <= 4 && afc::prod::advf_ok_for(sf.n, sf.m, cplv) && af + 512 <= 40960 && level > 0) {
       // 1: the predictor's tail in the corrector's advection; 2: also the corrector's tail + Heun average in the next
       // sim-step's predictor advection, inside a launch of several sim-steps
       P.fuse_tail = level > 1 ? 2 : 1;
@@ -659,7 +659,12 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   // (qx, qy: the projected predictor field of the fused advection passes -- only envs that run them carry it, so that
   // the slab of every other env is what it was: the placement search works on the slab's size)
   std::vector<AFC_AS1 float **> fields = {&P.ux, &P.uy, &P.p, &P.u0x, &P.u0y, &P.usx, &P.usy, &P.fx, &P.fy, &P.r, &P.d};
-  if (P.fuse_tail) {
+#if AFC_DEVHOOKS
+  const bool with_q = true;  // tools/ab_inproc.py --share-slab: instances with and without the fused passes share one layout
+#else
+  const bool with_q = P.fuse_tail != 0;
+#endif
+  if (with_q) {
     fields.push_back(&P.qx);
     fields.push_back(&P.qy);
   }

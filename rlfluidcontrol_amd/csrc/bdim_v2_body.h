@@ -3288,7 +3288,7 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
   const bool adv3_ok = adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024);
   // the predictor's projection tail inside the corrector's advection (advdif_v3f): the projected predictor field is then
   // Q, not B
-  const bool fuse = !AFC_DIAG && C <= 2 && adv3_ok && uni(P.fuse_tail) != 0 && uni(P.bc_fold) != 0 && advf_shape_ok(uni(P.n), uni(P.m), C);
+  const bool fuse = !AFC_DIAG && adv3_ok && uni(P.fuse_tail) != 0 && uni(P.bc_fold) != 0 && advf_ok_for(uni(P.n), uni(P.m), C);
 #pragma nounroll
   for (int half = 0; half < 2; ++half) {
     const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
@@ -3297,9 +3297,9 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
     float *pout = uni(half ? p0 : p1);
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (fuse && half) {
-      if constexpr (C <= 2) advdif_v3f<C, false>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
+      if constexpr (C <= 2 || AFC_FUSE_T2) advdif_v3f<(C > 2 ? 2 : C), false, (C > 2)>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
     } else if (fuse && heun_in) {
-      if constexpr (C <= 2) advdif_v3f<C, true>(P, Cx, Cy, Qx, Qy, Bx, By, lds, p0, shift, Ax, Ay);
+      if constexpr (C <= 2 || AFC_FUSE_T2) advdif_v3f<(C > 2 ? 2 : C), true, (C > 2)>(P, Cx, Cy, Qx, Qy, Bx, By, lds, p0, shift, Ax, Ay);
     } else if (adv3_ok)
       advdif_v3<(C > 2 ? 2 : C), C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);  // TAG = C: one instance per kernel instantiation
     else
@@ -3356,8 +3356,8 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
 template <int C>
 __device__ __forceinline__ bool heun_fusable(const StepParams &P) {
   const int adv3_ns = uni(P.adv_ns);
-  return !AFC_DIAG && C <= 2 && adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024) && uni(P.fuse_tail) > 1 && uni(P.bc_fold) != 0 &&
-         advf_shape_ok(uni(P.n), uni(P.m), C);
+  return !AFC_DIAG && adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024) && uni(P.fuse_tail) > 1 && uni(P.bc_fold) != 0 &&
+         advf_ok_for(uni(P.n), uni(P.m), C);
 }
 // the tail a sim-step left out, on its own (a launch that ends with one pending: the state in memory must be complete)
 __device__ __forceinline__ void heun_tail_only(const StepParams &P, size_t e, float shift, float *lds) {

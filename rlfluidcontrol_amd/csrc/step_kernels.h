@@ -129,7 +129,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   // a tail pending all the same, the tail runs on its own after it.
   bool heun_pending = false;
   bool can_defer = false;
-  if constexpr (CPL >= 1 && CPL <= 2 && !DIAG) can_defer = afc::AFC_MODE_NS::heun_fusable<CPL>(P);
+  if constexpr (CPL >= 1 && (CPL <= 2 || AFC_FUSE_T2) && !DIAG) can_defer = afc::AFC_MODE_NS::heun_fusable<CPL>(P);
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
     if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     __syncthreads();
     if (s_stop) break;
   }
-  if constexpr (CPL >= 1 && CPL <= 2 && !DIAG) {
+  if constexpr (CPL >= 1 && (CPL <= 2 || AFC_FUSE_T2) && !DIAG) {
     if (heun_pending) afc::AFC_MODE_NS::heun_tail_only(P, e, pshift, lds_dyn);
   }
   if (DIAG && CPL != 0) afc::gate_release(P, true);
