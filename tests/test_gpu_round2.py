@@ -369,6 +369,31 @@ def test_fused_tails_through_launches_of_many_sim_steps(envmod, res, exact):
             assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
 
 
+def test_fused_tails_when_the_launch_ends_on_the_clock(envmod):
+    """the launch loop of k_agent_step ends on the action window, on the step count or on t >= end_time (clientCFD.pde:36);
+    a sim-step leaves its Heun tail to the next one only if it knows that one follows.  end_time inside an action window:
+    the last sim-step of the episode must have completed the state itself -- same observations, done flags, step counts and
+    fields as the two-pass form, and a further call (which runs no sim-step) changes nothing."""
+    E = 6
+    a = np.linspace(-1, 1, 2 * E).reshape(E, 2).astype(np.float32)
+    out = []
+    for fuse in (1, -1):
+        g = envmod.AFCEnv(num_envs=E, resolution=8, reynolds=100, fuse_tail=fuse, end_time=1.2)
+        rec = []
+        for k in range(4):
+            obs, rew, done, ns = g.agent_step(a)
+            rec.append((obs.copy(), done.copy(), ns.copy()))
+        out.append((rec, [g.get_state(e) for e in (0, E - 1)]))
+        g.close()
+    (ra, sa), (rb, sb) = out
+    assert ra[-1][1].all() and ra[-1][2].max() == 0 and any(0 < r[2].max() < 16 for r in ra)  # the clock ran out inside a window
+    for (o1, d1, n1), (o2, d2, n2) in zip(ra, rb):
+        assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)) and np.array_equal(d1, d2) and np.array_equal(n1, n2)
+    for x, y in zip(sa, sb):
+        for f1, f2 in zip(x, y):
+            assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+
 def test_shipped_and_diagnostic_instantiations_agree_bit_for_bit(envmod):
     """afc::prod (dbg == 0) and afc::diag (any dbg != 0) are the same code with and without the diagnostics compiled in"""
     for exact in (1, 0):
