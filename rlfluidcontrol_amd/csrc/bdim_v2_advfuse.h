@@ -1,34 +1,36 @@
-// THE CORRECTOR'S ADVECTION WITH THE PREDICTOR'S PROJECTION TAIL INSIDE IT (included by bdim_v2_body.h, inside the
-// namespace of the instantiation).
+// A PROJECTION TAIL INSIDE THE ADVECTION PASS THAT FOLLOWS IT (included by bdim_v2_body.h, inside the namespace of the
+// instantiation).
 //
-// BDIM.update() ends with u.project: u -= c grad(p + s), u.setBC() (VectorField.pde:136-140); BDIM.update2() begins with
-// AdvDif of that field (BDIM.pde:90-93, VectorField.pde:170-179).  As two passes (project_tail_v2, then advdif_v3) the
-// projected field is written to memory (2 floats per cell) and read back (2 floats) a gigabyte of other traffic later.
-// Here the advection's row pipelines stage the RAW rows (the field as forcing + setBC left it in front of the solve), and
-// each wave projects a row IN ITS LDS RING, two rows ahead of the stencil that reads it:
+// u.project ends with u -= c grad(p + s), u.setBC() (VectorField.pde:136-140) -- in the corrector followed by the Heun
+// average u = (u + us) / 2 (BDIM.pde:95-96) -- and the next thing that happens to that field is AdvDif (BDIM.pde:82, 90-93;
+// VectorField.pde:170-179).  As two passes (project_tail_v2, then advdif_v3) the projected field is written to memory
+// (2 floats per cell) and read back (2 floats) a gigabyte of other traffic later -- beyond L2 and beyond the Infinity
+// Cache (tools/mall_test.hip).  Here the advection's row pipelines stage the RAW rows (F as forcing + setBC left it in
+// front of the solve) and each wave projects a row IN ITS LDS RING one iteration before its stencils read it:
 //
-//   * the raw velocity rows arrive by LDS-DMA exactly as advdif_v3's source rows do; so does the row of p, one row
-//     ahead, into a single row slot (p of the row above is the previous row's, kept in registers), and -- for rows that
-//     cross a body -- the two rows of face coefficients.  Nothing comes through registers asynchronously: a load whose
-//     destination the compiler may copy or spill before the hand-placed wait is a race (tried: loads by inline assembly
-//     into tied operands -- the compiler moved the set between registers while the load was in flight).  The three row
-//     slots are paid for by the base rows, which are single-buffered here (copied right after their use, one
-//     iteration ahead): 19 rows per wave instead of 18
+//   * everything arrives by LDS-DMA, as advdif_v3's source rows do: the raw velocity rows two rows ahead (rings of 6
+//     rows per component instead of 7), the row of p one row ahead into a single row slot (p of the row above is the
+//     previous row's, kept in registers), for rows that cross a body the two rows of face coefficients likewise, and
+//     the base rows (HEUN: the rows of us) double-buffered: 19 row slots per wave instead of advdif_v3's 18.  Nothing
+//     comes through registers asynchronously: a load whose destination the compiler may copy or spill before the
+//     hand-placed wait is a race (tried: loads by inline assembly into tied operands -- the compiler moved the set between
+//     registers while the load was in flight; wrong bits under load only)
 //   * the projected row is written back into the ring slot (with the wall columns setBC gives it) and -- by the wave
-//     that OWNS the row -- to the field `q`, which the Heun average at the end of the corrector reads as `us`
-//     (BDIM.pde:95-96).  q is a field of its own: the raw field stays intact, so the two halo rows either side of a
-//     wave's quarter are projected a second time by the neighbour, in its own ring, with the same operands -- no flags,
-//     no ordering between waves, no barrier
+//     that OWNS the row -- to the field `q`.  q is never the raw field: that stays intact, so the two halo rows either
+//     side of a wave's quarter are projected a second time by the neighbour, in its own ring, from the same operands --
+//     no flags, no ordering between waves, no barrier
 //   * what setbc_rows does after the tail moves to the owners of rows 1 and n-2: row 0 = the projected row 1, then
 //     u.x of row 1 = 1 (inflow); row n-1 = the projected row n-2 with the outflow correction 1 - mean(row n-2), the
 //     mean added in the reference's order (Field.pde:302-318) through v_readlane
 //
-// Same operands, same operations, same order as project_tail_v2 + setbc_rows + advdif_v3: the bits do not change.
+// Same operands, same operations, same order as project_tail_v2 + setbc_rows + advdif_v3: the bits do not change
+// (tests/test_gpu_parity.py::test_fused_projection_tail_is_bit_exact, tests/test_gpu_round2.py::test_fused_tails_*).
 // All waits are counted vmcnt waits formed from a running count of the wave's issued vector-memory operations and the
-// count at the operation waited for (`issued - tag`): the wave's operations complete in order.
+// count at the operation waited for (`issued - tag`): the wave's operations complete in order, and the producer's
+// operations per row vary (own rows store, halo rows do not; body rows copy two more rows; rows 1 and n-2 store twice).
 //
-// One column tile only (grids of at most 64*C interior columns: 256x128, 128x64), >= 8 rows per wave, folded walls.
-constexpr int kAdvfNS = 6;  // ring rows per component: i-2 .. i+3 (the raw copies run ONE row less ahead than advdif_v3's: the row after next)
+// One column tile (256x128, 128x64), >= 8 rows per wave, folded walls; two tiles behind AFC_FUSE_T2 (below).
+constexpr int kAdvfNS = 6;  // ring rows per component: i-2 .. i+3
 __device__ __host__ __forceinline__ int advf_lds_floats(int C) { return 4 * (2 * kAdvfNS + 7) * (64 * C + 4) + 4; }
 __device__ __host__ __forceinline__ bool advf_shape_ok(int n, int m, int C) {
   return (C == 1 || C == 2) && (m - 2) <= 64 * C && ((m - 2) % C) == 0 && ((n - 2) & 3) == 0 && (n - 2) >= 4 * 8;
