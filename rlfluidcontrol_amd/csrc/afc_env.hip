@@ -449,15 +449,16 @@ int afc_create(const afc_config *cfg, afc_env **out) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    int level = (cfg->fuse_tail > 0 || (cfg->fuse_tail == 0 && (long long)env->E >= (long long)cus)) ? 2 : 0;
+    int level = (cfg->fuse_tail > 0 || (cfg->fuse_tail == 0 && (long long)env->E >= (long long)cus)) ? 3 : 0;
 #if AFC_DEVHOOKS
-    // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1 lib.so:AFC_FUSE_TAIL=2 (1: only the predictor's tail)
-    if (const char *ft = getenv("AFC_FUSE_TAIL")) level = atoi(ft);
+    // tools/ab_inproc.py lib.so:AFC_FUSE_TAIL=0 lib.so:AFC_FUSE_TAIL=1 ... (bits: 1 the predictor's tail, 2 the corrector's; 3 both)
+    if (const char *ft = getenv("AFC_FUSE_TAIL")) level = atoi(ft) & 3;
 #endif
+    if (level & 2) level |= 1;  // (the second needs the first: `us` must not live in the field the predictor pass writes)
     if (P.impl != 0 && P.adv_ns && cplv <= 4 && afc::prod::advf_ok_for(sf.n, sf.m, cplv) && af + 512 <= 40960 && level > 0) {
-      // 1: the predictor's tail in the corrector's advection; 2: also the corrector's tail + Heun average in the next
+      // bit 0: the predictor's tail in the corrector's advection; bit 1: the corrector's tail + Heun average in the next
       // sim-step's predictor advection, inside a launch of several sim-steps
-      P.fuse_tail = level > 1 ? 2 : 1;
+      P.fuse_tail = level;
       if (af > env->lds_bytes_step) env->lds_bytes_step = af;
     }
   }
@@ -662,7 +663,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
 #if AFC_DEVHOOKS
   const bool with_q = true;  // tools/ab_inproc.py --share-slab: instances with and without the fused passes share one layout
 #else
-  const bool with_q = P.fuse_tail != 0;
+  const bool with_q = (P.fuse_tail & 1) != 0;
 #endif
   if (with_q) {
     fields.push_back(&P.qx);

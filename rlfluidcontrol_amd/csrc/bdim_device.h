@@ -111,7 +111,7 @@ struct StepParams {
   int adv_ns;          // ring depth (rows) of advdif_v3's per-wave row pipelines; 0 = use advdif_v2
   int head_v3;         // 1: the barrier-free head of the pressure solve (grids of 128 interior columns)
   int gs_mode;         // 0: MG.smooth in the reference's lexicographic order; 1: red-black perf mode
-  int fuse_tail;       // 1: the predictor's projection tail runs inside the corrector's advection (advdif_v3f), its result in qx / qy
+  int fuse_tail;       // bit 0: the predictor's projection tail runs inside the corrector's advection (advdif_v3f), its result in qx / qy; bit 1: the corrector's tail + Heun average inside the next sim-step's predictor advection
   int bottom_lb;       // first multigrid level of the LDS-resident bottom of the V-cycle (mg_bottom); 0 = none
   int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows

@@ -3288,7 +3288,12 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
   const bool adv3_ok = adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024);
   // the predictor's projection tail inside the corrector's advection (advdif_v3f): the projected predictor field is then
   // Q, not B
-  const bool fuse = !AFC_DIAG && adv3_ok && uni(P.fuse_tail) != 0 && uni(P.bc_fold) != 0 && advf_ok_for(uni(P.n), uni(P.m), C);
+  const int fuse_bits = (!AFC_DIAG && adv3_ok && uni(P.bc_fold) != 0 && advf_ok_for(uni(P.n), uni(P.m), C)) ? uni(P.fuse_tail) : 0;
+  const bool fuse = (fuse_bits & 1) != 0;    // the predictor's tail inside the corrector's advection: the projected predictor field is Q
+  // the corrector's tail + Heun average inside the next predictor's advection -- only together with the first: with `us` in B
+  // the pass would read the rows of us from the field it writes its result to
+  const bool fuse_h = fuse && (fuse_bits & 2) != 0;
+  float *const Ux = fuse ? Qx : Bx, *const Uy = fuse ? Qy : By;  // `us` of the Heun average
 #pragma nounroll
   for (int half = 0; half < 2; ++half) {
     const float *sx = uni(half ? Bx : Ax), *sy = uni(half ? By : Ay);
@@ -3298,8 +3303,8 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
     const bool fold = uni(P.bc_fold) != 0 && !(AFC_DBG_OF(P) & 0x80000000u);
     if (fuse && half) {
       if constexpr (C <= 2 || AFC_FUSE_T2) advdif_v3f<(C > 2 ? 2 : C), false, (C > 2)>(P, Bx, By, Ax, Ay, Cx, Cy, lds, p1, shift, Qx, Qy);
-    } else if (fuse && heun_in) {
-      if constexpr (C <= 2 || AFC_FUSE_T2) advdif_v3f<(C > 2 ? 2 : C), true, (C > 2)>(P, Cx, Cy, Qx, Qy, Bx, By, lds, p0, shift, Ax, Ay);
+    } else if (fuse_h && heun_in) {
+      if constexpr (C <= 2 || AFC_FUSE_T2) advdif_v3f<(C > 2 ? 2 : C), true, (C > 2)>(P, Cx, Cy, Ux, Uy, Bx, By, lds, p0, shift, Ax, Ay);
     } else if (adv3_ok)
       advdif_v3<(C > 2 ? 2 : C), C>(P, sx, sy, Ax, Ay, dx, dy, lds, fold);  // TAG = C: one instance per kernel instantiation
     else
@@ -3318,8 +3323,8 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
 #if AFC_DIAG
     if (pf.stop) pf.stop -= 8 * half;  // phases 3..6 of this half
 #endif
-    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, fuse ? Qx : Bx, fuse ? Qy : By, Ax, Ay, sm, &l, pf,
-                                 lds, first_after_action && half == 0, fuse && (half == 0 || defer_out));
+    const int it = project_v2<C>(half != 0, P, e, dx, dy, pin, pout, &shift, Ux, Uy, Ax, Ay, sm, &l, pf,
+                                 lds, first_after_action && half == 0, half == 0 ? fuse : (fuse_h && defer_out));
     if (pf.stop >= 3 && pf.stop <= 6) return;
 #if AFC_DIAG
     if (pf.stop) pf.stop += 8 * half;
@@ -3356,14 +3361,15 @@ __device__ __forceinline__ void sim_step_v2(const StepParams &P, size_t e, float
 template <int C>
 __device__ __forceinline__ bool heun_fusable(const StepParams &P) {
   const int adv3_ns = uni(P.adv_ns);
-  return !AFC_DIAG && adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024) && uni(P.fuse_tail) > 1 && uni(P.bc_fold) != 0 &&
+  return !AFC_DIAG && adv3_ns == kAdvNS && !(AFC_DBG_OF(P) & 1024) && (uni(P.fuse_tail) & 3) == 3 && uni(P.bc_fold) != 0 &&
          advf_ok_for(uni(P.n), uni(P.m), C);
 }
 // the tail a sim-step left out, on its own (a launch that ends with one pending: the state in memory must be complete)
 __device__ __forceinline__ void heun_tail_only(const StepParams &P, size_t e, float shift, float *lds) {
   const size_t eo = e * (size_t)P.Ns;
-  project_tail_v2(true, P, lds, uni(G(P.p) + eo), shift, uni(G(P.fx) + eo), uni(G(P.fy) + eo), uni(G(P.qx) + eo), uni(G(P.qy) + eo),
-                  uni(G(P.ux) + eo), uni(G(P.uy) + eo), true);
+  const bool q = (uni(P.fuse_tail) & 1) != 0;  // where `us` is: Q if the predictor's tail ran inside the corrector's advection, else B
+  project_tail_v2(true, P, lds, uni(G(P.p) + eo), shift, uni(G(P.fx) + eo), uni(G(P.fy) + eo), uni((q ? G(P.qx) : G(P.usx)) + eo),
+                  uni((q ? G(P.qy) : G(P.usy)) + eo), uni(G(P.ux) + eo), uni(G(P.uy) + eo), true);
 }
 
 #undef AFC_DBG_OF
