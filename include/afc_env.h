@@ -114,7 +114,11 @@ typedef struct afc_config {
                            tail runs in the next sim-step's predictor pass; same bits either way):
                            0 (default) = where it is faster -- one-tile grids (<= 128 interior columns) in launches of at
                            least one env per CU; 1 = wherever the grid allows it; -1 = never */
-  int32_t reserved2[1];
+  int32_t upleg;        /* the way back up a multigrid level (MG.pde:73-97: prolongation increment, smooth(4), increment):
+                           0 (default) = the four ordered sweeps by one wave marching DOWN THE ROWS (mg_up_tr, round 6) on the
+                           levels of 128 / 64 / 32 interior columns of grids up to 128 columns wide, the strip march elsewhere;
+                           1 = round 5's strip pipeline (mg_up_pipe), 2 = strip by strip with workgroup barriers
+                           (mg_up_smooth) -- both run the diagnostic instantiation of the kernels.  Same bits in every case */
 } afc_config;
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */

@@ -288,7 +288,7 @@ int sync_params(afc_env *env) {
 // the instantiation with the diagnostics compiled in runs only when one of them is switched on
 bool need_diag(const afc_env *env) {
   const StepParams &P = env->P;
-  return P.dbg != 0 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
+  return P.dbg != 0 || P.upleg != 0 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
 }
 
 // 0 = shipped kernels, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; diagnostics are not available in it)
@@ -347,6 +347,8 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (cfg->gs_mode == 1 && (cfg->stagger_us != 0 || cfg->reserved[0] != 0))
     return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) has no diagnostics: stagger_us and reserved[0] (dbg) must be 0");
   if (cfg->y_lengths * cfg->resolution > 256 && cfg->impl != 0) return fail(AFC_EINVAL, "afc_create: impl 2 supports up to 256 cells in y");
+  if (cfg->upleg < 0 || cfg->upleg > 2) return fail(AFC_EINVAL, "afc_create: upleg must be 0 (marching down the rows), 1 (strip pipeline) or 2 (barrier form)");
+  if (cfg->gs_mode == 1 && cfg->upleg != 0) return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) has its own up-leg: upleg must be 0");
   int ndev = 0;
   hipError_t he = hipGetDeviceCount(&ndev);
   if (he != hipSuccess || ndev < 1)
@@ -401,6 +403,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.impl = cfg->impl;
   P.gs_mode = cfg->gs_mode;
   P.dbg = cfg->reserved[0];
+  P.upleg = cfg->upleg;
   P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
   P.stagger_shift = (cfg->stagger_us >> 20) & 63;  // experimental: bits 0-3 = block-index shift, bits 4-5 = phases-2
   P.adv_rows = (sf.m <= 130) ? 16 : 8;
@@ -615,6 +618,23 @@ int afc_create(const afc_config *cfg, afc_env **out) {
     const int lb = afc::prod::bottom_first_level(P.lev, P.nlev);
     P.bottom_lb = (P.impl != 0 && lb >= 2 && lb <= P.nlev - 2 && afc::prod::bottom_shape_ok(P.lev, P.nlev) &&
                    (size_t)afc::prod::bottom_lds_floats(P.lev, P.nlev) * sizeof(float) <= env->lds_bytes) ? lb : 0;
+  }
+
+  // mg_up_tr (the sweeps marching down the rows): the levels above the bottom of the kernels for grids of up to 128
+  // columns whose shape it has and whose rings + special-cell table fit the LDS region -- bit 0 the shipped kernels'
+  // (whose region grows to hold them: still four workgroups per CU), bit 1 the diagnostic instantiation's
+  for (int l = 0; l < P.nlev; ++l) {
+    afc::LevelDesc &D = P.lev[l];
+    D.tm = 0;
+    const bool above_bottom = P.bottom_lb ? (l < P.bottom_lb) : (l < P.nlev - 1);
+    if (P.impl == 0 || cfg->gs_mode != 0 || env->cpl > 2 || !above_bottom || !afc::prod::tm_shape_ok(D.n, D.m)) continue;
+    const size_t need_prod = (size_t)afc::prod::tm_lds_floats(D.m, D.sp_i0, D.sp_i1, D.sp_j0, D.sp_j1) * sizeof(float);
+    const size_t need_diag = (size_t)afc::prod::tm_lds_floats(D.m, D.sp_i0, D.sp_i1, D.sp_j0, D.sp_j1, 24) * sizeof(float);
+    if (need_prod + 512 <= 40960) {
+      D.tm |= 1;
+      if (need_prod > env->lds_bytes_step) env->lds_bytes_step = need_prod;
+    }
+    if (need_diag <= env->lds_bytes) D.tm |= 2;
   }
 
   for (int l = 0, off = 0; l < P.nlev; ++l) {  // what bottom_level() needs per level
@@ -1435,7 +1455,7 @@ int afc_op_project(afc_env *env, float *ux, float *uy, float *p, int32_t *iters,
   else if (need_diag(env))
     afc::launch_op_project_diag(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
   else
-    afc::launch_op_project_prod(env->lds_bytes, env->stream, Pq, dit, dl, dsh);
+    afc::launch_op_project_prod(env->lds_bytes_step, env->stream, Pq, dit, dl, dsh);
   int rc = launch_check("k_op_project");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));
@@ -1473,7 +1493,7 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
   else if (need_diag(env) || P.impl == 0)
     afc::launch_op_mg_diag(env->lds_bytes, env->stream, Pq, dit, dl);
   else
-    afc::launch_op_mg_prod(env->lds_bytes, env->stream, Pq, dit, dl);
+    afc::launch_op_mg_prod(env->lds_bytes_step, env->stream, Pq, dit, dl);
   int rc = launch_check("k_op_mg");
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(env->stream));

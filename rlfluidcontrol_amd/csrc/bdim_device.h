@@ -51,6 +51,7 @@ struct LevelDesc {
   int dbg_copy;      // StepParams.dbg, reachable from an Lv (diagnostic switches)
   int mw_H;          // strip height of the multi-wave smoother on this level (rows per sweep per strip, <= 63)
   int rbw;           // perf mode: 1 = the level's up-leg runs as register-resident row pipelines (mg_up_rbw)
+  int tm;            // the up-leg with the sweeps marching down the rows (mg_up_tr) fits: bit 0 the shipped kernels' LDS region, bit 1 the diagnostic ones'
 };
 
 struct SampleDev {
@@ -116,6 +117,7 @@ struct StepParams {
   int head_v4;         // 1: the barrier-free head on grids of 132 .. 256 interior columns (head_v4)
   int down_v3;         // 1: coarse down-legs as barrier-free per-wave row pipelines (down_v3c) where the level's shape allows
   int bc_fold;         // 1: the row-streaming passes store the wall columns of u themselves, setBC is row work only (setbc_rows)
+  int upleg;           // afc_config.upleg: 0 = mg_up_tr where it applies, 1 = round 5's strip pipeline (mg_up_pipe), 2 = strip by strip with barriers (mg_up_smooth); 1 and 2 run the diagnostic instantiation
   const AFC_AS1 float *bottom_rec;  // its table: per level the planes {lw, le, ls, ln} / {inv, 0} / 0 / 0 per cell, levels bottom_lb .. nlev-1 back to back
   const AFC_AS1 int *band_x, *band_y;  // interior cells touched by the immersed-boundary forcing
   int nband_x, nband_y;

@@ -40,7 +40,7 @@ class AfcConfig(C.Structure):
         ("init_time", C.c_float), ("end_time", C.c_float), ("num_envs", C.c_int32),
         ("device", C.c_int32), ("mg_max_iters", C.c_int32), ("carry_quirk", C.c_int32),
         ("reward_penalty", C.c_float), ("exact_sums", C.c_int32), ("impl", C.c_int32), ("stagger_us", C.c_int32), ("reserved", C.c_int32 * 1),
-        ("gs_mode", C.c_int32), ("fuse_tail", C.c_int32), ("reserved2", C.c_int32 * 1),
+        ("gs_mode", C.c_int32), ("fuse_tail", C.c_int32), ("upleg", C.c_int32),
     ]
 
 

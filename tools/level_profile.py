@@ -18,7 +18,7 @@ xi = (5 * rng.uniform(-1, 1, (E, 2))).astype(np.float32)
 
 
 def run(nrows):
-    g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=(nrows << 20) | (1 << 30 if nrows == 0 else 0))
+    g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=(nrows << 20) | (1 << 30 if nrows == 0 else 0), upleg=int(os.environ.get("UPLEG", "0")))
     g.set_reset_state(z["u"], z["v"], z["p"])
     g.reset()
     for _ in range(3):

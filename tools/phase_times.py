@@ -28,7 +28,7 @@ def main():
     xi = (5 * rng.uniform(-1, 1, (E, 2))).astype(np.float32)
     ts = []
     for st in STOPS:
-        g = env.AFCEnv(num_envs=E, resolution=res, reynolds=Re, dbg=st << 12)
+        g = env.AFCEnv(num_envs=E, resolution=res, reynolds=Re, dbg=st << 12, upleg=int(os.environ.get("UPLEG", "0")))
         if z is not None:
             g.set_reset_state(z["u"], z["v"], z["p"])
             g.reset()
