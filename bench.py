@@ -40,15 +40,20 @@ WORKLOADS = {(16, 100, 1024): "BASELINE.json configs[1]",
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the kernel sources: ties a committed PMC traffic figure to the code it was
-    measured on"""
+    """sha256 (first 16 hex digits) over the CODE of the kernel sources -- comments and white space stripped, so that
+    editing a comment does not cut a committed PMC traffic figure loose from the code it was measured on"""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rlfluidcontrol_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip", ".cpp")):
+            txt = open(os.path.join(d, f), "r", errors="replace").read()
+            txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)      # block comments
+            txt = re.sub(r"//[^\n]*", " ", txt)                   # line comments (none of the sources has `//` in a string)
+            txt = re.sub(r"\s+", " ", txt)
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(txt.encode())
     return h.hexdigest()[:16]
 
 

@@ -114,12 +114,26 @@ typedef struct afc_config {
                            tail runs in the next sim-step's predictor pass; same bits either way):
                            0 (default) = where it is faster -- one-tile grids (<= 128 interior columns) in launches of at
                            least one env per CU; 1 = wherever the grid allows it; -1 = never */
-  int32_t upleg;        /* the way back up a multigrid level (MG.pde:73-97: prolongation increment, smooth(4), increment):
-                           0 (default) = the four ordered sweeps by one wave marching DOWN THE ROWS (mg_up_tr, round 6) on the
-                           levels of 128 / 64 / 32 interior columns of grids up to 128 columns wide, the strip march elsewhere;
-                           1 = round 5's strip pipeline (mg_up_pipe), 2 = strip by strip with workgroup barriers
-                           (mg_up_smooth) -- both run the diagnostic instantiation of the kernels.  Same bits in every case */
+  int32_t upleg;        /* the way back up a multigrid level (MG.pde:73-97: prolongation increment, smooth(4), increment; the
+                           reference's lexicographic order and the same bits in every case):
+                           1 = round 5's strip pipeline (mg_up_pipe: one wave marches 16-row strips along the rows, three
+                               waves exit and fill behind it);
+                           3 = the four ordered sweeps by one wave marching DOWN THE ROWS (mg_up_tr, round 6) on the levels
+                               of 128 / 64 / 32 interior columns of grids up to 128 columns wide -- half the latency chain,
+                               the same instruction count: -14 % per launch for one env, -9 % at one env per CU, +4 % at
+                               four per CU (a kernel instantiation of its own, afc::lat);
+                           0 (default) = by occupancy: 3 for launches of fewer than 2.5 envs per CU, else 1;
+                           2 = strip by strip with workgroup barriers (mg_up_smooth; diagnostic instantiation) */
 } afc_config;
+
+/* Environment variables the SHIPPED library reads (all at afc_create; none of them changes a result):
+ *   AFC_PLACEMENT_TRIALS=n  candidates of the placement search (default up to 32; 1 = no search), see afc_placement_info
+ *   AFC_ARENA=<MiB>         size of the env's arena for its small device buffers (default: sized from the case)
+ *   AFC_RBW=<level mask>    perf mode (gs_mode 1) only: the levels whose up-leg runs as register-resident row pipelines
+ *   AFC_PRINT_ALLOC=1       prints the placement search, the slab and the multigrid levels' special cells to stderr
+ * (the Python binding additionally honours AFC_ENV_LIB, and AFC_DBG together with AFC_DBG_ENABLE=1).  Builds with
+ * -DAFC_DEVHOOKS=1 (tools/build_variant.sh; never the shipped library) also read AFC_SLAB_PTR / AFC_EXPORT_SLAB /
+ * AFC_ALLOC_MODE / AFC_FUSE_TAIL / AFC_TR_MASK for tools/ab_inproc.py. */
 
 /* fills *cfg with the reference-native case (res 24, Re 500, 1 env, device 0) */
 int afc_default_config(afc_config *cfg);
@@ -240,6 +254,10 @@ int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *me
 /* 1 if this env's step kernels run the projection tails inside the advection passes that follow them
  * (afc_config.fuse_tail, advdif_v3f), 0 if they are separate passes; negative on error */
 int afc_fused_tail(const afc_env *env);
+
+/* The up-leg this env's step kernels run (afc_config.upleg resolved: 1 = strip pipeline, 2 = barrier form, 3 = the sweeps
+ * marching down the rows where the level has their shape); negative on error */
+int afc_upleg(const afc_env *env);
 
 #ifdef __cplusplus
 }

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libafc_env.so")
 # translation units, compiled in parallel: the C ABI + small kernels, the three instantiations of the step kernels
-# (shipped / diagnostics compiled in / perf mode: step_kernels.h), the host geometry
-SOURCES = ["afc_env.hip", "step_prod.hip", "step_diag.hip", "step_perf.hip", "geometry.cpp"]
+# (shipped / diagnostics compiled in / perf mode / few envs per CU: step_kernels.h), the host geometry
+SOURCES = ["afc_env.hip", "step_prod.hip", "step_diag.hip", "step_perf.hip", "step_lat.hip", "geometry.cpp"]
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]

@@ -184,6 +184,7 @@ struct afc_env {
   long long *d_stamps = nullptr;
   size_t lds_bytes = 0;
   size_t lds_bytes_step = 0;  // dynamic LDS of the shipped / perf step kernels (>= lds_bytes: + the fused advection's three row slots)
+  size_t lds_bytes_lat = 0;   // ... of afc::lat's (>= lds_bytes_step: the rings + special-cell table of mg_up_tr)
   StepParams *d_P = nullptr;  // device copy of P for the step kernels
   bool p_dirty = true;
   int cpl = 0;  // kernel instantiation: columns per lane (0 = reference kernels)
@@ -288,13 +289,15 @@ int sync_params(afc_env *env) {
 // the instantiation with the diagnostics compiled in runs only when one of them is switched on
 bool need_diag(const afc_env *env) {
   const StepParams &P = env->P;
-  return P.dbg != 0 || P.upleg != 0 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
+  return P.dbg != 0 || P.upleg == 2 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
 }
 
-// 0 = shipped kernels, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; diagnostics are not available in it)
+// 0 = shipped kernels, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; diagnostics are not available in it),
+// 3 = the shipped code with the up-legs marching down the rows (afc::lat: launches of few envs per CU)
 int launch_mode(const afc_env *env) {
   if (env->P.gs_mode == 1) return 2;
-  return need_diag(env) ? 1 : 0;
+  if (need_diag(env)) return 1;
+  return (env->P.upleg == 3 && env->cpl >= 1 && env->cpl <= 2) ? 3 : 0;
 }
 
 int launch_check(const char *what) {
@@ -347,7 +350,9 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   if (cfg->gs_mode == 1 && (cfg->stagger_us != 0 || cfg->reserved[0] != 0))
     return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) has no diagnostics: stagger_us and reserved[0] (dbg) must be 0");
   if (cfg->y_lengths * cfg->resolution > 256 && cfg->impl != 0) return fail(AFC_EINVAL, "afc_create: impl 2 supports up to 256 cells in y");
-  if (cfg->upleg < 0 || cfg->upleg > 2) return fail(AFC_EINVAL, "afc_create: upleg must be 0 (marching down the rows), 1 (strip pipeline) or 2 (barrier form)");
+  if (cfg->fuse_tail < -1 || cfg->fuse_tail > 1) return fail(AFC_EINVAL, "afc_create: fuse_tail must be -1 (never), 0 (where it is faster) or 1 (wherever the grid allows)");
+  if (cfg->upleg < 0 || cfg->upleg > 3)
+    return fail(AFC_EINVAL, "afc_create: upleg must be 0 (by occupancy), 1 (strip pipeline), 2 (barrier form) or 3 (marching down the rows)");
   if (cfg->gs_mode == 1 && cfg->upleg != 0) return fail(AFC_EINVAL, "afc_create: gs_mode 1 (perf mode) has its own up-leg: upleg must be 0");
   int ndev = 0;
   hipError_t he = hipGetDeviceCount(&ndev);
@@ -403,7 +408,7 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   P.impl = cfg->impl;
   P.gs_mode = cfg->gs_mode;
   P.dbg = cfg->reserved[0];
-  P.upleg = cfg->upleg;
+  P.upleg = cfg->upleg;  // (0 is resolved below, once the levels are known)
   P.stagger_ticks = (cfg->stagger_us & 0xFFFFF) * 100;
   P.stagger_shift = (cfg->stagger_us >> 20) & 63;  // experimental: bits 0-3 = block-index shift, bits 4-5 = phases-2
   P.adv_rows = (sf.m <= 130) ? 16 : 8;
@@ -539,6 +544,13 @@ int afc_create(const afc_config *cfg, afc_env **out) {
         if (i < 3 || i > sf.n - 4 || j < 3 || j > sf.m - 4) clear = false;
       }
     P.bc_fold = (P.impl != 0 && clear && sf.m <= afc::kRowCap) ? 1 : 0;
+    // the fused advection passes stage rows WITH their wall columns: no fusion without the folded walls (the device gates
+    // on bc_fold too; decided here so that afc_fused_tail() and the slab's q fields follow what really runs).  Perf mode
+    // (validation only) keeps the two-pass form: no test drives its kernels through the fused passes.
+    if (!P.bc_fold || cfg->gs_mode == 1) {
+      P.fuse_tail = 0;
+      env->lds_bytes_step = env->lds_bytes;
+    }
   }
 #undef UP
   // multigrid hierarchy, all levels concatenated
@@ -621,21 +633,39 @@ int afc_create(const afc_config *cfg, afc_env **out) {
   }
 
   // mg_up_tr (the sweeps marching down the rows): the levels above the bottom of the kernels for grids of up to 128
-  // columns whose shape it has and whose rings + special-cell table fit the LDS region -- bit 0 the shipped kernels'
-  // (whose region grows to hold them: still four workgroups per CU), bit 1 the diagnostic instantiation's
+  // columns whose shape it has and whose rings + special-cell table fit the LDS region -- bit 0 that of afc::lat (sized
+  // for them: still four workgroups per CU), bit 1 the diagnostic instantiation's
+  env->lds_bytes_lat = env->lds_bytes_step;
+  bool any_tm = false;
   for (int l = 0; l < P.nlev; ++l) {
     afc::LevelDesc &D = P.lev[l];
     D.tm = 0;
     const bool above_bottom = P.bottom_lb ? (l < P.bottom_lb) : (l < P.nlev - 1);
     if (P.impl == 0 || cfg->gs_mode != 0 || env->cpl > 2 || !above_bottom || !afc::prod::tm_shape_ok(D.n, D.m)) continue;
-    const size_t need_prod = (size_t)afc::prod::tm_lds_floats(D.m, D.sp_i0, D.sp_i1, D.sp_j0, D.sp_j1) * sizeof(float);
+    const size_t need_lat = (size_t)afc::prod::tm_lds_floats(D.m, D.sp_i0, D.sp_i1, D.sp_j0, D.sp_j1) * sizeof(float);
     const size_t need_diag = (size_t)afc::prod::tm_lds_floats(D.m, D.sp_i0, D.sp_i1, D.sp_j0, D.sp_j1, 24) * sizeof(float);
-    if (need_prod + 512 <= 40960) {
+    if (need_lat + 512 <= 40960) {
       D.tm |= 1;
-      if (need_prod > env->lds_bytes_step) env->lds_bytes_step = need_prod;
+      any_tm = true;
+      if (need_lat > env->lds_bytes_lat) env->lds_bytes_lat = need_lat;
     }
     if (need_diag <= env->lds_bytes) D.tm |= 2;
+#if AFC_DEVHOOKS
+    if (const char *tmk = getenv("AFC_TR_MASK")) {  // tools/ab_inproc.py lib.so:AFC_TR_MASK=<bit l: level l marches down the rows>
+      if (!((atoi(tmk) >> l) & 1)) D.tm = 0;
+    }
+#endif
   }
+  // afc_config.upleg = 0: by occupancy.  Measured on the same memory (tools/ab_inproc.py --share-slab, 256x128, per launch
+  // of 16 sim-steps, mg_up_tr against the strip pipeline): 1 env -13.8 %, 256 envs (one per CU) -8.8 %, 512 -0.8 %,
+  // 768 +5.4 %, 1024 +3.9 % -- the shorter latency chain pays while a CU has idle issue slots to spend on it
+  if (P.upleg == 0) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    P.upleg = (any_tm && 2 * (long long)env->E < 5 * (long long)cus) ? 3 : 1;
+  }
+  if (P.upleg == 3 && !any_tm) P.upleg = 1;
 
   for (int l = 0, off = 0; l < P.nlev; ++l) {  // what bottom_level() needs per level
     P.lev[l].bot_off = 0;
@@ -788,16 +818,26 @@ int afc_create(const afc_config *cfg, afc_env **out) {
           rate.push_back(probe(q, 4));
           if (!probe_ok) break;  // (the candidate stays in the list with rate 0: it is a usable allocation)
           // enough: at least SIXTEEN candidates seen and the best stands 3.5 % above their MEDIAN (the two kinds of placement
-          // are 4-5 % apart in this probe; the median is of the slow kind, four in five are) -- or the candidates held
-          // take more than a third of the device's free memory.  (Six was too few: the slow kind alone spreads over 3 %
-          // in this probe, and four of twenty-one development runs stopped early on the best of the slow ones; a
-          // candidate costs ~3 ms.)
+          // are 4-5 % apart in this probe; the median is of the slow kind, four in five are).  (Six was too few: the slow
+          // kind alone spreads over 3 % in this probe, and four of twenty-one development runs stopped early on the best
+          // of the slow ones; a candidate costs ~3 ms.)  The number of candidates was capped above at a quarter of the
+          // free memory AT THAT TIME; somebody else (a learner, another rank's afc_create) may be allocating on the same
+          // device meanwhile, so every fourth candidate looks again and stops once less is free than the candidates
+          // already hold -- afc_create is still best not raced with other large allocations on its device.
           std::vector<float> srt(rate);
           std::sort(srt.begin(), srt.end());
           const float med = srt[srt.size() / 2], hi = srt.back();
           env->place_best = hi;
           env->place_median = med;
           if (cand.size() >= 16 && hi >= 1.035f * med) break;
+          if ((cand.size() & 3) == 0) {
+            size_t fr2 = 0, tot2 = 0;
+            if (hipMemGetInfo(&fr2, &tot2) != hipSuccess) {
+              (void)hipGetLastError();
+              break;
+            }
+            if (fr2 < cand.size() * total * sizeof(float)) break;
+          }
         }
         env->place_trials = (int)cand.size();
         if (e0) (void)hipEventDestroy(e0);
@@ -1106,6 +1146,7 @@ int afc_sim_step(afc_env *env, const float *xi_m, float *force) {
   switch (env->cpl == 0 ? 1 : launch_mode(env)) {  // the reference kernels (cpl 0) live in the diagnostic unit
     case 1: afc::launch_sim_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dxi, dforce); break;
     case 2: afc::launch_sim_step_perf(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dxi, dforce); break;
+    case 3: afc::launch_sim_step_lat(env->cpl, env->E, env->lds_bytes_lat, env->stream, env->d_P, dxi, dforce); break;
     default: afc::launch_sim_step_prod(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dxi, dforce);
   }
   int rc = launch_check("k_sim_step");
@@ -1146,6 +1187,7 @@ int afc_agent_step(afc_env *env, const float *action, float *obs, float *reward,
   switch (env->cpl == 0 ? 1 : launch_mode(env)) {
     case 1: afc::launch_agent_step_diag(env->cpl, env->E, env->lds_bytes, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
     case 2: afc::launch_agent_step_perf(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
+    case 3: afc::launch_agent_step_lat(env->cpl, env->E, env->lds_bytes_lat, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps); break;
     default: afc::launch_agent_step_prod(env->cpl, env->E, env->lds_bytes_step, env->stream, env->d_P, dact, dobs, drew, ddone, dns, max_steps);
   }
   int rc = launch_check("k_agent_step");
@@ -1509,7 +1551,14 @@ int afc_op_mg_solve(afc_env *env, float *x, const float *b, int32_t *iters, floa
 
 int afc_fused_tail(const afc_env *env) {
   if (!env) return fail(AFC_EINVAL, "afc_fused_tail: null");
-  return env->P.fuse_tail != 0 ? 1 : 0;
+  // (the diagnostic instantiation -- dbg switches, a start stagger, phase stamps -- keeps the tails as passes of their own)
+  return (env->P.fuse_tail != 0 && launch_mode(env) != 1) ? 1 : 0;
+}
+
+int afc_upleg(const afc_env *env) {
+  if (!env) return fail(AFC_EINVAL, "afc_upleg: null");
+  if (env->P.gs_mode == 1 || env->P.impl == 0) return 2;  // (perf mode / the reference kernels: their own strip-by-strip forms)
+  return env->P.upleg;
 }
 
 int afc_placement_info(afc_env *env, int32_t *trials, float *best_gbs, float *median_gbs) {

@@ -1,4 +1,4 @@
-// bdim_v2.h -- the optimised phases of the per-env BDIM step (bdim_v2_body.h), compiled twice:
+// bdim_v2.h -- the optimised phases of the per-env BDIM step (bdim_v2_body.h), compiled four times:
 //   afc::prod  the shipped instantiation: no experiment switches, no phase marks, no stop codes, no gates
 //   afc::perf  the shipped code with the red-black smoother (perf mode, see below)
 //   afc::diag  the same code with the diagnostics of tools/ compiled in (StepParams.dbg, Prof marks, stop codes,
@@ -11,20 +11,41 @@
 #if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 0
 #define AFC_DIAG 0
 #define AFC_RB 0
+#define AFC_TR 0
 #define AFC_NS prod
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
+#undef AFC_TR
+#undef AFC_NS
+#endif
+
+// afc::lat: the shipped code with the up-legs of the multigrid levels marching DOWN THE ROWS (mg_up_tr, round 6) instead of
+// round 5's strip pipeline: the shorter latency chain (one env alone -14 % per launch, one env per CU -9 %), which four
+// workgroups per CU do not need (+3 % there).  The host picks it for launches of fewer than 2.5 envs per CU
+// (afc_config.upleg).  An instantiation of its own: compiled into afc::prod as well, its call sites alone cost the
+// 1024-env launch 1.9 % (the register allocation of the one big step kernel).
+#if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 3
+#define AFC_DIAG 0
+#define AFC_RB 0
+#define AFC_TR 1
+#define AFC_NS lat
+#include "bdim_v2_body.h"
+#undef AFC_DIAG
+#undef AFC_RB
+#undef AFC_TR
 #undef AFC_NS
 #endif
 
 #if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 1
 #define AFC_DIAG 1
 #define AFC_RB 0
+#define AFC_TR 1
 #define AFC_NS diag
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
+#undef AFC_TR
 #undef AFC_NS
 #endif
 
@@ -34,9 +55,11 @@
 #if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 2
 #define AFC_DIAG 0
 #define AFC_RB 1
+#define AFC_TR 0
 #define AFC_NS perf
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
+#undef AFC_TR
 #undef AFC_NS
 #endif

@@ -2980,6 +2980,7 @@ __device__ AFC_BOT_ATTR void mg_bottom(const StepParams &P, size_t e, int LB, fl
 
 // MGsolver (MG.pde:30-38): fused head (first iteration), straightforward descending leg on the
 // coarse levels, fused ascending leg.  L0.x is the buffer the solution is left in.
+#if AFC_TR
 // mg_up_tr by the level's width (16 CB interior columns)
 __device__ __forceinline__ void up_tr(const bool HASC, const Lv &F, const Lv &Cc, bool need_r, float *lds, float *rr_out,
                                       float *linf_out, ProfT &pf, float *xsum_out, const int rmode) {
@@ -2998,6 +2999,7 @@ __device__ __forceinline__ void up_tr(const bool HASC, const Lv &F, const Lv &Cc
     if (xsum_out) *xsum_out = o.xs;
   }
 }
+#endif
 
 // (forced inline: as a function of its own it would not inherit the kernels' register cap -- launch bounds apply to
 // kernels only -- and its 248 VGPRs would halve the occupancy of every kernel that calls it)
@@ -3082,10 +3084,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
       // on the coarse levels measured +0.3 % (512x256) and +23.7 % (384x192) per launch -- their register allocation
       // answers the extra branch with reloads inside the loops; they keep round 4's up-leg unchanged)
       // round 6: the sweeps marching down the rows (mg_up_tr) where the host found the level's shape and room for its rings
-      // (LevelDesc::tm); afc_config.upleg = 1 / 2 keep round 5's strip pipeline (diagnostic instantiation only) / the barrier form
-      const bool tr = !AFC_RB && H0 == 16 && ((uni(F.desc->tm) >> (AFC_DIAG ? 1 : 0)) & 1) != 0 && !(AFC_DBG_OF(P) & (256 | 4)) &&
-                      uni(P.upleg) == 0;
-      const bool pipe = AFC_DIAG && !AFC_RB && H0 == 16 && up_pipe_shape_ok(F.n, F.m) && !(AFC_DBG_OF(P) & 256) && uni(P.upleg) != 2;
+      // (LevelDesc::tm) -- in afc::lat, the instantiation for launches of few envs per CU, and selectable in afc::diag
+      // (afc_config.upleg: 1 = the strip pipeline, 2 = the barrier form, else mg_up_tr)
+      const bool tr = AFC_TR && !AFC_RB && H0 == 16 && ((uni(F.desc->tm) >> (AFC_DIAG ? 1 : 0)) & 1) != 0 &&
+                      !(AFC_DBG_OF(P) & (256 | 4)) && !(AFC_DIAG && (uni(P.upleg) == 1 || uni(P.upleg) == 2));
+      const bool pipe = !(AFC_TR && !AFC_DIAG) && !AFC_RB && H0 == 16 && up_pipe_shape_ok(F.n, F.m) && !(AFC_DBG_OF(P) & 256) &&
+                        !(AFC_DIAG && uni(P.upleg) == 2);
 #if AFC_RB
       // perf mode: the register-resident row pipelines where the level has their shape; on the finest level only when
       // the new residual stays unwritten (a wave reads the old r of its neighbours' rows)
@@ -3098,9 +3102,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
         mg_up_smooth_mw(hasc, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else
 #endif
+#if AFC_TR
       if (tr)
         up_tr(true, F, Cc, l == 0, lds, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
-      else if (pipe)
+      else
+#endif
+      if (pipe)
         mg_up_pipe(true, F, Cc, l == 0, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
       else if (H0 != 16 && l == 0)
         mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr, &linf, pf, &xsum, lazy_r ? 1 : 0);
@@ -3113,9 +3120,12 @@ __device__ __forceinline__ int mg_solve_v2(const StepParams &P, size_t e, const 
           mg_up_smooth_mw(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
 #endif
+#if AFC_TR
         if (tr)
           up_tr(true, F, Cc, true, lds, &rr2, &linf2, pf, nullptr, 2);
-        else if (pipe)
+        else
+#endif
+        if (pipe)
           mg_up_pipe(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);
         else
           mg_up_smooth<H0>(true, F, Cc, true, lds, sm, &rr2, &linf2, pf, nullptr, 2);

@@ -568,9 +568,7 @@ __device__ __noinline__ void tm_march(const TmArgs A_) {
 // two register sets and the call of the march push the allocation of the ~200 KB step kernel over the edge -- scratch
 // reloads inside the row loops of every other phase (+38 % per launch at 1024 envs, measured).  The LDS region comes as an
 // address and becomes an explicit LDS pointer again inside, so that the accesses stay ds_* instructions.
-#if AFC_DIAG
-#define AFC_TR_ATTR inline
-#else
+#ifndef AFC_TR_ATTR
 #define AFC_TR_ATTR __noinline__
 #endif
 struct TrOut {

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
 }
 
 // unit-level operators on env 0 (same device functions as the step, chosen the way sim_step_v2 chooses them)
+#if AFC_MODE != 3  // (afc::lat carries the step kernels only)
 #if AFC_MODE != 2
 template <int MODE>
 __global__ __launch_bounds__(afc::kThreads, 4) void k_op_advdif(StepParams P, int same) {
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_op_mg(StepParams P, int *i
     *linf = l;
   }
 }
+#endif  // AFC_MODE != 3
 
 
 }  // namespace
@@ -320,7 +322,10 @@ void AFC_FN(launch_sim_step_)(int cpl, int E, size_t lds, hipStream_t st, const 
 #if AFC_MODE == 1
     LAUNCH(0);
 #endif
-    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+    LAUNCH(1); LAUNCH(2);
+#if AFC_MODE != 3  // (afc::lat: grids of up to 128 columns only -- the kernels whose levels mg_up_tr serves)
+    LAUNCH(3); LAUNCH(4);
+#endif
 #undef LAUNCH
   }
 }
@@ -331,10 +336,14 @@ void AFC_FN(launch_agent_step_)(int cpl, int E, size_t lds, hipStream_t st, cons
 #if AFC_MODE == 1
     LAUNCH(0);
 #endif
-    LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4);
+    LAUNCH(1); LAUNCH(2);
+#if AFC_MODE != 3
+    LAUNCH(3); LAUNCH(4);
+#endif
 #undef LAUNCH
   }
 }
+#if AFC_MODE != 3
 #if AFC_MODE != 2  // (the advection pass has no smoother in it: a perf-mode env runs the shipped operator kernel)
 void AFC_FN(launch_op_advdif_)(size_t lds, hipStream_t st, const StepParams &P, int same) {
   hipLaunchKernelGGL(k_op_advdif<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, same);
@@ -346,6 +355,7 @@ void AFC_FN(launch_op_project_)(size_t lds, hipStream_t st, const StepParams &P,
 void AFC_FN(launch_op_mg_)(size_t lds, hipStream_t st, const StepParams &P, int *dit, float *dl) {
   hipLaunchKernelGGL(k_op_mg<AFC_MODE>, dim3(1), dim3(kThreads), lds, st, P, dit, dl);
 }
+#endif  // AFC_MODE != 3
 #if AFC_MODE == 1
 int occupancy_agent_step_diag(int cpl, size_t lds, int *per_cu) {
   switch (cpl) {

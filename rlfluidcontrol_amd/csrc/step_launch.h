@@ -1,4 +1,4 @@
-// step_launch.h -- host entry points of the three step-kernel translation units (step_kernels.h)
+// step_launch.h -- host entry points of the four step-kernel translation units (step_kernels.h)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,6 +16,7 @@ namespace afc {
 AFC_DECL_MODE(prod)
 AFC_DECL_MODE(diag)
 AFC_DECL_MODE(perf)
+AFC_DECL_MODE(lat)
 #undef AFC_DECL_MODE
 void launch_op_advdif_prod(size_t lds, hipStream_t st, const StepParams &P, int same);
 void launch_op_advdif_diag(size_t lds, hipStream_t st, const StepParams &P, int same);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "afc_set_field", "afc_get_probes", "afc_get_static", "afc_level_dims", "afc_op_advdif",
     "afc_op_mg_solve", "afc_op_setbc_u", "afc_profile_phases", "afc_format_float_java", "afc_get_cfl",
     "afc_get_window_complete", "afc_get_mg_histogram", "afc_measure_copy_rate", "afc_op_project",
-    "afc_placement_info", "afc_fused_tail",
+    "afc_placement_info", "afc_fused_tail", "afc_upleg",
 ]
 
 
@@ -104,6 +104,7 @@ def load_library():
     try:  # round 5
         L.afc_placement_info.argtypes = [vp, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.afc_fused_tail.argtypes = [vp]
+        L.afc_upleg.argtypes = [vp]
     except AttributeError:
         if not os.environ.get("AFC_ENV_LIB"):
             raise
@@ -312,6 +313,13 @@ class AFCEnv:
         if r < 0:
             self._ck(r, "afc_fused_tail")
         return bool(r)
+
+    def upleg(self):
+        """the up-leg the step kernels run (afc_config.upleg resolved): 1 strip pipeline, 2 barrier form, 3 marching down the rows"""
+        r = self._L.afc_upleg(self._h)
+        if r < 0:
+            self._ck(r, "afc_upleg")
+        return int(r)
 
     def diverged(self):
         out = np.empty(self.num_envs, np.uint8)

@@ -186,11 +186,13 @@ class Agent:
     keep the reference's names and meaning; states/actions may carry any batch size."""
 
     # Transitions per env and episode of the reference's case (clientCFD.pde: 16-step windows from t = 1 to t = 50 at
-    # dt = 0.0075): what a rank's replay ring has to hold per env to cover one whole episode.
+    # dt = 0.0075: 408 requests, 407 transitions): what a rank's replay ring has to hold per env to cover one whole
+    # episode -- the DEFAULT; a trainer on another time stepping passes steps_per_episode (train.py: the request count of
+    # its episode_plan).
     STEPS_PER_EPISODE = 410
 
     def __init__(self, state_dim, action_dim, explore_noise="Gaussian", device="cpu", seed=None, num_envs=1, world=1,
-                 replay_capacity=None, replay_episodes=3):
+                 replay_capacity=None, replay_episodes=3, steps_per_episode=None):
         self.world = world  # > 1: sharded learner (gradients averaged over the ranks, see _sync_grads)
         self.num_envs = num_envs
         self.n_grad_allreduce = 0
@@ -217,9 +219,12 @@ class Agent:
         # step, so the ring must hold whole episodes of ALL its envs or training never sees the early part of an
         # episode (1024 envs x 410 steps = 420 k per episode: a 1 M / world share would keep the last ~120 agent steps
         # only).  max(1 M, replay_episodes x num_envs x STEPS_PER_EPISODE) transitions of 32 bytes each.
+        # (job-wide that is world x this -- against the reference's single 1 M FIFO: a sampling deviation of the batched
+        # trainer, recorded as `replay_capacity` in train.py's episode log)
         local_envs = max(1, int(num_envs) // max(int(world), 1))  # (num_envs counts the envs of ALL ranks)
+        self.steps_per_episode = int(steps_per_episode) if steps_per_episode else self.STEPS_PER_EPISODE
         self.replay_capacity = int(replay_capacity) if replay_capacity else max(
-            self.bfs, int(replay_episodes) * local_envs * self.STEPS_PER_EPISODE)
+            self.bfs, int(replay_episodes) * local_envs * self.steps_per_episode)
         self.replay_buffer = ReplayBuffer(state_dim, action_dim, self.replay_capacity, device=self.device)
         self.step_count = self.total_step_count = self.episode_count = self.train_count = 0
 
@@ -394,7 +399,7 @@ class BatchedLearner:
     and at the end of the episode turn them into transitions and run `train_steps` TD3 iterations."""
 
     def __init__(self, num_envs, device="cpu", filter="None", explore_noise="Gaussian", one_action=False, seed=None,
-                 shard=None):
+                 shard=None, steps_per_episode=None):
         """num_envs = ALL envs this learner acts for (every rank evaluates the same actor on the gathered obs).
         shard = (rank, world): the learner is sharded -- this rank stores the transitions of ITS envs only (the block
         [rank*E, (rank+1)*E) of the env axis) and trains on a 1/world share of every batch with averaged gradients."""
@@ -403,7 +408,7 @@ class BatchedLearner:
         self.one_action = one_action
         self.action_dim = 1 if one_action else 2
         self.agent = Agent(2, self.action_dim, explore_noise=explore_noise, device=device, seed=seed, num_envs=num_envs,
-                           world=self.world)
+                           world=self.world, steps_per_episode=steps_per_episode)
         self.filter = KalmanFilter() if filter == "Kalman" else NoneFilter()
         self.state_record, self.action_record = [], []
 

@@ -3,7 +3,7 @@
 The reference trains one env through XML-RPC: 408 requests per episode, then `train(1000)`
 (clientCFD.pde:35-85, server.py:148-170).  Here E envs of one GPU run the same episode protocol
 in lock-step and the learner lives on the same device: observations, actions, records and the
-replay buffer never leave HBM; at the end of an episode the E x 407 transitions are stored and
+replay buffer never leave HBM; at the end of an episode the E x 407 transitions (408 requests) are stored and
 `train_steps` TD3 iterations run.
 
     python -m rlfluidcontrol_amd.train --envs 1024 --episodes 2 --train-steps 1000
@@ -132,14 +132,16 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
     vec = ShardedVecEnv(HipBackend(g, dev), num_envs, device=dev)
     if batch_size and batch_size % vec.world:
         raise ValueError("batch_size %d must be a multiple of the world size %d (sharded learner)" % (batch_size, vec.world))
-    learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed,
-                                 shard=(vec.rank, vec.world))
-    if batch_size:
-        learner.agent.bs = batch_size
     c = g.cfg
     # the sketch globals (callLearn, Cd, Cl) survive an episode roll-over in the reference's carry mode: the phase of the
     # averaging window then depends on history, and the loop polls the device instead of following a plan
-    plan = None if c.carry_quirk else episode_plan(c.resolution, c.t_step, c.init_time, c.end_time, c.substeps)
+    full_plan = episode_plan(c.resolution, c.t_step, c.init_time, c.end_time, c.substeps)
+    plan = None if c.carry_quirk else full_plan
+    # (the replay ring holds whole episodes of this env configuration: its requests per episode, not the reference case's)
+    learner = td3.BatchedLearner(vec.world * num_envs, device=dev, filter=filter, explore_noise=explore_noise, seed=seed,
+                                 shard=(vec.rank, vec.world), steps_per_episode=full_plan[1] + 2)
+    if batch_size:
+        learner.agent.bs = batch_size
     history = []
     for ep in range(episodes):
         g.reset()
@@ -156,7 +158,7 @@ def train(num_envs=1024, resolution=16, reynolds=100, episodes=1, train_steps=10
         rec = dict(episode=ep + 1, requests=n, mean_reward=mean_r, rollout_s=t1 - t0, train_s=t2 - t1,
                    buffer=learner.agent.replay_buffer.size, td3_iters=learner.agent.total_step_count,
                    world=vec.world, envs_total=vec.world * num_envs, collectives=vec.n_collectives,
-                   grad_allreduces=learner.agent.n_grad_allreduce)
+                   grad_allreduces=learner.agent.n_grad_allreduce, replay_capacity=learner.agent.replay_capacity)
         history.append(rec)
         log(json.dumps(rec))
     g.close()

@@ -16,8 +16,9 @@ from rlfluidcontrol_amd import build, codeobj
 def test_step_kernels_keep_four_workgroups_per_cu():
     kernels = codeobj.kernel_resources(build.build())
     step = {n: v for n, v in kernels.items() if "k_agent_step" in n or "k_sim_step" in n}
-    # both kernels: CPL = 0 (reference kernels, diagnostic unit) + CPL = 1..4 x {shipped, diagnostics, perf mode}
-    assert len(step) == 2 * (1 + 4 * 3), sorted(step)
+    # both kernels: CPL = 0 (reference kernels, diagnostic unit) + CPL = 1..4 x {shipped, diagnostics, perf mode} +
+    # CPL = 1, 2 of afc::lat (the up-legs marching down the rows: grids of up to 128 columns)
+    assert len(step) == 2 * (1 + 4 * 3 + 2), sorted(step)
     for n, v in step.items():
         assert v["vgpr_count"] + v["agpr_count"] <= 128, (n, v)
         # MI355X_MICROARCH.md: 256-thread blocks per CU <= floor(800 / (ceil(sgpr/16)*16 + 16))
@@ -27,8 +28,11 @@ def test_step_kernels_keep_four_workgroups_per_cu():
             # spill budget (bytes per lane): what is spilled sits outside the innermost loops (tools/loop_scan.py)
             # (the projection tail is a function of its own since round 4: its callee-saved registers are part of the figure;
             # the diagnostic instantiation, which nobody times, gets a little more room)
+            # (afc::lat and afc::diag call mg_up_tr / tm_march, functions of their own: the callee-saved registers of the two
+            # nested calls are part of the figure -- saved once per call, six calls per sim-step)
             diag = n.split("ELi")[-1].startswith("1E")
-            assert v["private_segment_fixed_size"] <= ((768 if diag else 640) if "k_agent_step" in n else 1024), (n, v)
+            lat = n.split("ELi")[-1].startswith("3E")
+            assert v["private_segment_fixed_size"] <= ((1152 if (diag or lat) else 640) if "k_agent_step" in n else 1280), (n, v)
     shipped = {n: v for n, v in step.items() if n.split("ELi")[-1].startswith("0E") and "ILi0E" not in n}
     assert len(shipped) == 8
     for n, v in shipped.items():

@@ -489,3 +489,67 @@ def test_pipelined_upleg_at_full_occupancy_is_deterministic_and_equals_the_barri
     same(a1, run(0, 0))
     assert a1[2][1:].sum() > 0  # some solves took a second V-cycle: the replay of the finest up-leg ran too
     same(run(0, 1), run(256, 1))
+
+
+def _run_upleg(envmod, upleg, exact, res, E, N=3, init_time=0.05, start=None):
+    rng = np.random.default_rng(11)
+    g = envmod.AFCEnv(num_envs=E, resolution=res, reynolds=100, exact_sums=exact, init_time=init_time, upleg=upleg)
+    assert g.upleg() == (upleg if upleg else (3 if E < 640 else 1))
+    if start is not None:
+        g.set_reset_state(start["u"], start["v"], start["p"])
+        g.reset()
+    rec = []
+    for _ in range(N):
+        obs, rew, done, ns = g.agent_step(rng.uniform(-1, 1, (E, 2)).astype(np.float32))
+        rec.append((obs.copy(), rew.copy(), ns.copy()))
+    st = [g.get_state(e) for e in range(0, E, max(1, E // 8))]
+    h = g.mg_histogram()
+    g.close()
+    return rec, st, h
+
+
+def _same_run(a, b, bits=True):
+    (ra, sa, ha), (rb, sb, hb) = a, b
+    assert np.array_equal(ha, hb)
+    for (o1, w1, n1), (o2, w2, n2) in zip(ra, rb):
+        assert np.array_equal(n1, n2)
+        if bits:
+            assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)) and np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+        else:
+            assert np.allclose(o1, o2, rtol=5e-5, atol=5e-5) and np.allclose(w1, w2, rtol=5e-5, atol=5e-5)
+    for x, y in zip(sa, sb):
+        for f1, f2, tol in zip(x, y, (5e-6, 5e-6, 5e-4 * max(1.0, float(np.abs(x[2]).max())))):
+            if bits:
+                assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+            else:
+                assert float(np.abs(f1 - f2).max()) <= tol
+
+
+@pytest.mark.parametrize("res", [8, 16])
+def test_uplegs_agree(envmod, res):
+    """afc_config.upleg: the strip pipeline (1: afc::prod), the barrier form (2: afc::diag) and the four sweeps marching down
+    the rows (3: afc::lat, what launches of few envs per CU run by default) do the same arithmetic in the same order: agent
+    steps through the impulsive start (several V-cycles per solve: the lazy-residual replay runs too) with 40 different
+    actions, in parity mode bit for bit -- observations, iteration histogram, fields.  In the default mode the three cut
+    the level into different pieces, so the partial sums of r.r and sum(p) are added in another order: equal iteration
+    counts, results within the default mode's tolerance (as for the other strip shapes, test_experiment_paths_...)."""
+    for exact in (1, 0):
+        ref = _run_upleg(envmod, 1, exact, res, 40)
+        assert ref[2][1:].sum() > 0
+        for u in (3, 2, 0):
+            _same_run(ref, _run_upleg(envmod, u, exact, res, 40), bits=(exact == 1))
+
+
+def test_rows_march_at_one_env_per_cu_is_deterministic_and_equals_the_barrier_form(envmod):
+    """race detector for mg_up_tr (the march, the filling wave and the two exiting waves hand ring rows over through three
+    counters in LDS) under the load it ships for: 256 envs = one per CU, random actions, 6 agent steps from the developed
+    wake -- two runs must agree bit for bit (a timing-dependent hazard would not), and in parity mode the march down the
+    rows must agree bit for bit with the barrier form; then the same at 1024 envs (upleg = 3 forced: four per CU, the
+    occupancy it is NOT the default for).  tests/test_tmarch_schedule_model.py: the schedule itself on the CPU."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wake_res16_re100.npz"))
+    a = _run_upleg(envmod, 0, 0, 16, 256, N=6, init_time=1.0, start=z)
+    _same_run(a, _run_upleg(envmod, 0, 0, 16, 256, N=6, init_time=1.0, start=z))
+    _same_run(_run_upleg(envmod, 3, 1, 16, 256, N=4, init_time=1.0, start=z), _run_upleg(envmod, 2, 1, 16, 256, N=4, init_time=1.0, start=z))
+    b = _run_upleg(envmod, 3, 0, 16, 1024, N=4, init_time=1.0, start=z)
+    _same_run(b, _run_upleg(envmod, 3, 0, 16, 1024, N=4, init_time=1.0, start=z))
+    _same_run(_run_upleg(envmod, 3, 1, 16, 1024, N=3, init_time=1.0, start=z), _run_upleg(envmod, 1, 1, 16, 1024, N=3, init_time=1.0, start=z))

@@ -9,7 +9,7 @@ out=$root/tools/bin/libafc_$name.so
 tmp=$(mktemp -d /tmp/afcvar_XXXX)
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function -DAFC_DEVHOOKS=1 -I$root/include $*"
 pids=()
-for s in afc_env.hip step_prod.hip step_diag.hip step_perf.hip geometry.cpp; do
+for s in afc_env.hip step_prod.hip step_diag.hip step_perf.hip step_lat.hip geometry.cpp; do
   /opt/rocm/bin/hipcc $FLAGS -c -o $tmp/${s%.*}.o $root/rlfluidcontrol_amd/csrc/$s > $tmp/${s%.*}.log 2>&1 &
   pids+=($!)
 done
