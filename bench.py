@@ -32,8 +32,8 @@ DEFAULT_INIT = {(16, 100): os.path.join(GOLDEN, "wake_res16_re100.npz"),
                 (24, 500): os.path.join(GOLDEN, "init_bdim_res24.npz")}
 # BASELINE.json workloads by (res, Re, envs per GPU)
 # HBM traffic per launch measured with rocprofv3 --pmc on exactly these kernel sources (tools/pmc_traffic.py), by workload
-TRAFFIC_FILES = {(16, 100, 1024): "r5_hbm_traffic.json", (32, 400, 1024): "r5_hbm_traffic_cfg4.json",
-                 (24, 500, 1024): "r5_hbm_traffic_native.json"}
+TRAFFIC_FILES = {(16, 100, 1024): "r6_hbm_traffic.json", (32, 400, 1024): "r6_hbm_traffic_cfg4.json",
+                 (24, 500, 1024): "r6_hbm_traffic_native.json"}
 WORKLOADS = {(16, 100, 1024): "BASELINE.json configs[1]",
              (32, 400, 1024): "BASELINE.json configs[3]",
              (24, 500, 1024): "reference-native 384x192 Re500 (init.bdim)"}
@@ -193,6 +193,8 @@ def main():
                     help="state (.npz with u, v, p) to start from; default: the committed state of the workload "
                          "(developed wake for 256x128 Re 100 and 512x256 Re 400, the reference's init.bdim for 384x192 "
                          "Re 500), else the free stream")
+    ap.add_argument("--upleg", type=int, default=0,
+                    help="afc_config.upleg: 0 by occupancy (default), 1 strip pipeline, 2 barrier form, 3 marching down the rows")
     ap.add_argument("--gs-mode", type=int, default=0,
                     help="0 = the reference's lexicographic Gauss-Seidel (headline); 1 = red-black perf mode (separate line)")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -250,7 +252,7 @@ def main():
         from rlfluidcontrol_amd import build, env as envmod
         build.build()
         g = envmod.AFCEnv(num_envs=E, resolution=args.res, reynolds=args.reynolds, device=local_rank,
-                          stagger_us=args.stagger_us, dbg=args.dbg, gs_mode=args.gs_mode)
+                          stagger_us=args.stagger_us, dbg=args.dbg, gs_mode=args.gs_mode, upleg=args.upleg)
         eff_dbg = int(g.cfg.reserved[0])  # includes AFC_DBG from the environment: recorded in the line
         if args.init and os.path.exists(args.init):
             z = np.load(args.init)
@@ -387,6 +389,7 @@ def main():
                        "envs_per_gpu": E, "grid": "%dx%d" % (16 * args.res, 8 * args.res), "reynolds": args.reynolds,
                        "sim_steps_per_agent_step": 16, "parallelism": "env-sharded x%d" % world,
                        "gs_order": "red-black (perf mode)" if args.gs_mode else "lexicographic (reference order)",
+                       "upleg": (g.upleg() if hasattr(g, "upleg") else None),
                        "dbg": eff_dbg, "kernel_src_sha16": kernel_source_hash(), "mg_iters_last": [int(it[:, 0].max()), int(it[:, 1].max())],
                        "mg_iters_histogram": {("%d" % (k + 1)) if k < 7 else ">=8": int(hist[k]) for k in range(8) if hist[k]}},
             "timing": {"repeats": len(passes), "reported": "median pass", "ms_per_step_all_passes":

@@ -114,8 +114,8 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       const unsigned ln_ = lane_fresh();                                               \
       if (ln_ < (unsigned)LQ) {                                                        \
         const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                  \
-        lds_dma16<(AFC_NT & 1) != 0>(sxc, so_, ring + (unsigned)s_next * PRB);         \
-        lds_dma16<(AFC_NT & 1) != 0>(syc, so_, ring + (unsigned)(s_next + NS) * PRB);  \
+        lds_dma16(sxc, so_, ring + (unsigned)s_next * PRB);                            \
+        lds_dma16(syc, so_, ring + (unsigned)(s_next + NS) * PRB);                     \
       }                                                                                \
       issued += 2;                                                                     \
     }                                                                                  \
@@ -128,8 +128,8 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
     if (ln_ < (unsigned)LQ) {                                                          \
       const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
       const unsigned lb_ = bslot + (unsigned)(2 * ((row) & 1)) * PRB;                  \
-      lds_dma16<(AFC_NT & 1) != 0>(bxc, so_, lb_);                                     \
-      lds_dma16<(AFC_NT & 1) != 0>(byc, so_, lb_ + PRB);                               \
+      lds_dma16(bxc, so_, lb_);                                                        \
+      lds_dma16(byc, so_, lb_ + PRB);                                                  \
     }                                                                                  \
     issued += 2;                                                                       \
   }
@@ -139,7 +139,7 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
     const unsigned ln_ = lane_fresh();                                                 \
     const unsigned so_ = 4u * (unsigned)((g) * m) + 16u * ln_;                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slots' readers are done */ \
-    if (ln_ < (unsigned)LQ) lds_dma16<(AFC_NT & 32) != 0>(ppc, so_, pslot);            \
+    if (ln_ < (unsigned)LQ) lds_dma16(ppc, so_, pslot);                                \
     issued += 1;                                                                       \
     if ((g) >= sp0 && (g) <= sp1) {                                                    \
       if (ln_ < (unsigned)LQ) {                                                        \
@@ -226,13 +226,13 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
           if (own) {
             if (first || last) {
               const unsigned gb = 4u * (unsigned)(grow * m + (first ? 0 : m - 1));
-              st1b_p<(AFC_NT & 2) != 0>(qx_, gb, aw);
-              st1b_p<(AFC_NT & 2) != 0>(qy_, gb, awv);
+              st1b(qx_, gb, aw);
+              st1b(qy_, gb, awv);
             }
             if (on) {
               const unsigned ob = 4u * (unsigned)(grow * m + j0);
-              stCb_p<(AFC_NT & 2) != 0, C>(qx_, ob, au);
-              stCb_p<(AFC_NT & 2) != 0, C>(qy_, ob, av);
+              __builtin_memcpy((char *)qx_ + ob, au, sizeof(float) * C);
+              __builtin_memcpy((char *)qy_ + ob, av, sizeof(float) * C);
             }
             issued += ST;
           }
@@ -297,7 +297,7 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
         for (int g = g0 - 1; g <= i_first + 2; ++g) {
           const int k = g - (i_first - 3);  // 0 .. 5
           const unsigned slot = (k < 2) ? ring + (unsigned)(5 + k * NS) * PRB : bslot + (unsigned)(k - 2) * PRB;
-          if (ln_ < (unsigned)LQ) lds_dma16<(AFC_NT & 32) != 0>(ppc, 4u * (unsigned)(g * m) + 16u * ln_, slot);
+          if (ln_ < (unsigned)LQ) lds_dma16(ppc, 4u * (unsigned)(g * m) + 16u * ln_, slot);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int k0 = (g0 - 1) - (i_first - 3);
@@ -328,7 +328,7 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
       // per round trip -- three round trips instead of six
       const unsigned ln_ = lane_fresh();
       auto p_to = [&](const int g, const int k) {
-        if (ln_ < (unsigned)LQ) lds_dma16<(AFC_NT & 32) != 0>(ppc, 4u * (unsigned)(g * m) + 16u * ln_, pslot + (unsigned)k * PRB);
+        if (ln_ < (unsigned)LQ) lds_dma16(ppc, 4u * (unsigned)(g * m) + 16u * ln_, pslot + (unsigned)k * PRB);
         issued += 1;
       };
       for (int q = 0; q < 5; ++q) {  // row g0 + q (ring slot q), its p in slot (q + 1) % 3
@@ -505,13 +505,13 @@ __device__ AFC_ADV_ATTR void advdif_v3f(const StepParams &P, const float *__rest
         const bool first = (ln_ == 0u) && (tcol == 0), last = (ln_ == (unsigned)(lanes_on - 1)) && (tcol == ncol - 1);
         if (first || last) {
           const unsigned gb = 4u * (unsigned)(i * m + (first ? 0 : m - 1));
-          st1b_p<(AFC_NT & 2) != 0>(dx, gb, first ? oxv[0] : oxv[C - 1]);
-          st1b_p<(AFC_NT & 2) != 0>(dy, gb, first ? oyv[0] : 0.f);
+          st1b(dx, gb, first ? oxv[0] : oxv[C - 1]);
+          st1b(dy, gb, first ? oyv[0] : 0.f);
         }
         if (first) oyv[0] = 0.f;
         if (ln_ < (unsigned)lanes_on) {
-          stCb_p<(AFC_NT & 2) != 0, C>(dx, ob, oxv);
-          stCb_p<(AFC_NT & 2) != 0, C>(dy, ob, oyv);
+          __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
+          __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
         }
         issued += ST;
       }

@@ -180,59 +180,6 @@ __device__ __forceinline__ float ld1b(const float *base, unsigned boff) {
 __device__ __forceinline__ void st4b(float *base, unsigned boff, const F4 &v) { __builtin_memcpy((char *)base + boff, &v, 16); }
 __device__ __forceinline__ void st1b(float *base, unsigned boff, float v) { __builtin_memcpy((char *)base + boff, &v, 4); }
 
-// Cache-policy experiment (AFC_NT, a bit mask; 0 = every access with the default policy): accesses of data that is
-// read once / not read again before a gigabyte of other traffic has passed carry the `nt` (non-temporal) bit, so that
-// they do not displace what IS re-read soon (the coarse levels, halo rows, p between the up-leg and the next advection)
-// from L2 and the Infinity Cache.  Bits: 1 = the advection's LDS-DMA copies of velocity rows (source + base), 2 = the
-// advection's stores (result + q), 4 = the solve head's store of r, 8 = the head's last read of a velocity row,
-// 16 = the up-leg's read of r, 32 = the advection's copies of p rows.  Same bits in memory either way.
-#ifndef AFC_NT
-#define AFC_NT 0
-#endif
-typedef float f4u4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f2u4 __attribute__((ext_vector_type(2), aligned(4)));
-template <bool NT>
-__device__ __forceinline__ F4 ld4b_p(const float *base, unsigned boff) {
-  if constexpr (NT) {
-    const f4u4 t = __builtin_nontemporal_load((const f4u4 *)((const char *)base + boff));
-    F4 r;
-    r.v[0] = t.x, r.v[1] = t.y, r.v[2] = t.z, r.v[3] = t.w;
-    return r;
-  } else {
-    return ld4b(base, boff);
-  }
-}
-template <bool NT>
-__device__ __forceinline__ float ld1b_p(const float *base, unsigned boff) {
-  if constexpr (NT) return __builtin_nontemporal_load((const float *)((const char *)base + boff));
-  else return ld1b(base, boff);
-}
-template <bool NT>
-__device__ __forceinline__ void st4b_p(float *base, unsigned boff, const F4 &v) {
-  if constexpr (NT) {
-    const f4u4 t = {v.v[0], v.v[1], v.v[2], v.v[3]};
-    __builtin_nontemporal_store(t, (f4u4 *)((char *)base + boff));
-  } else {
-    st4b(base, boff, v);
-  }
-}
-template <bool NT>
-__device__ __forceinline__ void st1b_p(float *base, unsigned boff, float v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, (float *)((char *)base + boff));
-  else st1b(base, boff, v);
-}
-template <bool NT, int C>
-__device__ __forceinline__ void stCb_p(float *base, unsigned boff, const float (&v)[C]) {
-  if constexpr (NT && C == 2) {
-    const f2u4 t = {v[0], v[1]};
-    __builtin_nontemporal_store(t, (f2u4 *)((char *)base + boff));
-  } else if constexpr (NT && C == 1) {
-    __builtin_nontemporal_store(v[0], (float *)((char *)base + boff));
-  } else {
-    __builtin_memcpy((char *)base + boff, v, sizeof(float) * C);
-  }
-}
-
 // One QUICK face value (VectorField.bho, VectorField.pde:202-219) for the face between cell L
 // and cell H = L+1 along one axis.  bLm = b[L-1], bHp = b[H+1]; uf = face velocity (positive:
 // flow from L to H); okL/okH = "upwind cell is not in the fallback zone" (VectorField.pde:212).
@@ -516,13 +463,12 @@ __device__ __forceinline__ void wait_vm_le(int K) {
 // in front of it with no branch, branch target or other copy in between, and no other implicit reader of m0 exists.
 // (Saving and restoring m0 around each copy instead would cost two scalar instructions per row and field in the
 // issue-bound advection.)
-template <bool NT = false>
+// (Cache policy, round 6: the same copies with the `nt` bit -- and non-temporal stores of the advection's results, of the
+// head's r, non-temporal last reads in the head and the up-leg -- measured on the same memory at 1024 envs: +0.3 ... +2.4 %
+// per launch in every combination; what is streamed once here is re-read a phase later, from the Infinity Cache if at all.)
 __device__ __forceinline__ void lds_dma16(const float *sbase, unsigned voff, unsigned ldsaddr) {
   const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)ldsaddr);  // uniform by construction; pins it to an SGPR
-  if constexpr (NT)
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(uni(sbase)), "s"(la) : "memory", "m0");
-  else
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uni(sbase)), "s"(la) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uni(sbase)), "s"(la) : "memory", "m0");
 }
 
 // advdif_v3: per wave a ring of kAdvNS rows per field plus two rows per base field, row pitch 64*C + 4 floats
@@ -603,8 +549,8 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
     const unsigned ln_ = lane_fresh();                                                 \
     if (r_next >= 0 && r_next <= r_hi && ln_ < (unsigned)LQ) {                         \
       const unsigned so_ = 4u * (unsigned)(r_next * m) + 16u * ln_;                    \
-      lds_dma16<(AFC_NT & 1) != 0>(sxc, so_, ring + (unsigned)s_next * PRB);           \
-      lds_dma16<(AFC_NT & 1) != 0>(syc, so_, ring + (unsigned)(s_next + NS) * PRB);    \
+      lds_dma16(sxc, so_, ring + (unsigned)s_next * PRB);                              \
+      lds_dma16(syc, so_, ring + (unsigned)(s_next + NS) * PRB);                       \
     }                                                                                  \
     ++r_next;                                                                          \
     s_next = (s_next + 1 == NS) ? 0 : s_next + 1;                                      \
@@ -615,8 +561,8 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
     if (ln_ < (unsigned)LQ) {                                                          \
       const unsigned so_ = 4u * (unsigned)((row) * m) + 16u * ln_;                     \
       const unsigned lb_ = ring + (unsigned)(2 * NS + 2 * ((row) & 1)) * PRB;          \
-      lds_dma16<(AFC_NT & 1) != 0>(bxc, so_, lb_);                                     \
-      lds_dma16<(AFC_NT & 1) != 0>(byc, so_, lb_ + PRB);                               \
+      lds_dma16(bxc, so_, lb_);                                                        \
+      lds_dma16(byc, so_, lb_ + PRB);                                                  \
     }                                                                                  \
   }
     for (int q = 0; q < NS; ++q) ADV3_STAGE()  // rows i_first-2 .. i_first+4
@@ -775,14 +721,14 @@ __device__ AFC_ADV_ATTR void advdif_v3(const StepParams &P, const float *__restr
         const bool first = (ln_ == 0u) && (tcol == 0), last = (ln_ == (unsigned)(lanes_on - 1)) && (tcol == ncol - 1);
         if (first || last) {
           const unsigned gb = 4u * (unsigned)(i * m + (first ? 0 : m - 1));
-          st1b_p<(AFC_NT & 2) != 0>(dx, gb, first ? oxv[0] : oxv[C - 1]);
-          st1b_p<(AFC_NT & 2) != 0>(dy, gb, first ? oyv[0] : 0.f);
+          st1b(dx, gb, first ? oxv[0] : oxv[C - 1]);
+          st1b(dy, gb, first ? oyv[0] : 0.f);
         }
         if (first) oyv[0] = 0.f;
       }
       if (ln_ < (unsigned)lanes_on) {  // (a tile of 96 columns leaves the upper 16 lanes idle)
-        stCb_p<(AFC_NT & 2) != 0, C>(dx, ob, oxv);
-        stCb_p<(AFC_NT & 2) != 0, C>(dy, ob, oyv);
+        __builtin_memcpy((char *)dx + ob, oxv, sizeof(float) * C);
+        __builtin_memcpy((char *)dy + ob, oyv, sizeof(float) * C);
       }
       asm volatile("" ::: "memory");
       if (t == 0) ADV3_STAGE()  // row i+5 replaces row i-2, whose last reader was this row's west face
@@ -1246,11 +1192,7 @@ __device__ __forceinline__ FillIn fill_load(const UpGeom &U, const bool HASC, in
   for (int e = 0; e < 4; ++e) in.r.v[e] = in.a[e] = 0.f;
   in.w1 = in.w2 = in.e1 = in.e2 = 0.f;
   if (g <= U.n_) {
-    if constexpr ((AFC_NT & 16) != 0) {
-      const f4u4 t = __builtin_nontemporal_load((const f4u4 *)(U.F->r + g * U.m + 1 + 4 * c4));
-      in.r.v[0] = t.x, in.r.v[1] = t.y, in.r.v[2] = t.z, in.r.v[3] = t.w;
-    } else
-      in.r = load4u(U.F->r + g * U.m + 1 + 4 * c4);
+    in.r = load4u(U.F->r + g * U.m + 1 + 4 * c4);
     if (HASC) {
       const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > U.n_) ? U.n_ : g + 1;
       const float *xa = U.Cc->x + ((g - 1) / 2 + 1) * U.mc + 2 * c4;  // coarse cols 2c4 .. 2c4+3
@@ -1470,6 +1412,8 @@ __device__ __forceinline__ void exit_apply(const UpGeom &U, const bool HASC, con
     }
   }
 }
+
+#include "bdim_v2_uplean.h"
 
 // Strip geometry of the up-leg: a strip brings kStripH new rows into the rings; the smoother runs in stages whose row
 // ranges are shifted up by one row each (stage s covers rows I0-s .. I0-s+kStripH-1), kStageShift = stages - 1.
@@ -2204,7 +2148,7 @@ __device__ AFC_HEAD_ATTR void head_v3(const StepParams &P, const Lv &L0, const L
     if (R_ >= (lo_ok) && R_ <= (hi_ok)) {                                                                          \
       const unsigned kb_ = 4u * (unsigned)(R_ * m + 1 + 4 * c4_);                                                  \
       const bool sp_ = ((R0) + 1 >= sp_i0) && ((R0) <= sp_i1);                                                     \
-      const F4 uxc = ld4b_p<(AFC_NT & 8) != 0>(ux, kb_), uxe = ld4b(ux, kb_ + 4u * m), uyc = ld4b_p<(AFC_NT & 8) != 0>(uy, kb_); \
+      const F4 uxc = ld4b(ux, kb_), uxe = ld4b(ux, kb_ + 4u * m), uyc = ld4b(uy, kb_);                             \
       const float uyn = ld1b(uy, kb_ + 16u);                                                                       \
       const F4 pc = ld4b(pin, kb_), pw = ld4b(pin, kb_ - 4u * m), pe = ld4b(pin, kb_ + 4u * m);                    \
       const float psl = ld1b(pin, kb_ - 4u), pnr = ld1b(pin, kb_ + 16u);                                           \
@@ -2297,7 +2241,7 @@ __device__ AFC_HEAD_ATTR void head_v3(const StepParams &P, const Lv &L0, const L
         xo.v[e] = (c_pc.v[e] + shift) + d;                                                     // MG.pde:95
       }
       st4b(pout, kb, xo);
-      st4b_p<(AFC_NT & 4) != 0>(r, kb, ro);
+      st4b(r, kb, ro);
       // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
       if (c4 == 0) st1b(pout, kb - 4u, (c_psl + shift) + d6[1]);
       if (c4 == CPR - 1) st1b(pout, kb + 16u, (c_pnr + shift) + d6[4]);
@@ -2469,7 +2413,7 @@ __device__ AFC_HEAD_ATTR void head_v4(const StepParams &P, const Lv &L0, const L
         xo.v[e] = (c.pc.v[e] + shift) + d;                                                     // MG.pde:95
       }
       st4b(pout, kb, xo);
-      st4b_p<(AFC_NT & 4) != 0>(r, kb, ro);
+      st4b(r, kb, ro);
       // ghosts mirror the adjacent interior d (d.setBC(), Field.pde:211-224)
       if (c4 == 0) st1b(pout, kb - 4u, (c.psl + shift) + d6[1]);
       if (c4 == CPR - 1) st1b(pout, kb + 16u, (c.pnr + shift) + d6[4]);

@@ -55,7 +55,7 @@ __device__ __host__ __forceinline__ bool tm_shape_ok(int n, int m) {
 __device__ __host__ __forceinline__ int tm_lds_floats(int m, int sp_i0, int sp_i1, int sp_j0, int sp_j1, int nr8 = TMC<8>::NR) {
   const int CB = tm_cb(m - 2);
   const int PW = 16 * CB + 4, NR = (CB == 8) ? nr8 : (CB == 4 ? TMC<4>::NR : TMC<2>::NR);
-  return 8 + 2 * NR * PW + PW + tm_tab_floats(CB, sp_i0, sp_i1, sp_j0, sp_j1) + 2 * CB + 16 + 2 + 64 + 6;
+  return 8 + 2 * NR * PW + PW + tm_tab_floats(CB, sp_i0, sp_i1, sp_j0, sp_j1) + 2 * CB + 16 + 2 + 64 + 1 + 5;
 }
 
 #ifdef AFC_TM_PROF  // development (tools/upleg_bench.hip): time stamps of workgroup 0
@@ -242,216 +242,29 @@ __device__ __forceinline__ void tm_step(TmState<CB> &S, const TmConst<CB> &Q) {
 #ifndef AFC_TM_SLEEP
 #define AFC_TM_SLEEP 1
 #endif
-#ifndef AFC_TM_SPINCAP
-#define AFC_TM_SPINCAP 4000000  // DEVELOPMENT DEFAULT (round 6, while the protocol is young): remove before shipping
-#endif
-// a wait on one of the counters (wave-uniform); AFC_TM_SPINCAP bounds every spin (development: a protocol error then
-// shows as wrong bits instead of a hung GPU)
-__device__ __forceinline__ void tm_wait(const lds_i *w, int need) {
-#ifdef AFC_TM_SPINCAP
-  for (int it = 0; it < AFC_TM_SPINCAP && uni(*(volatile const lds_i *)w) < need; ++it) __builtin_amdgcn_s_sleep(AFC_TM_SLEEP);
-#else
-  while (uni(*(volatile const lds_i *)w) < need) __builtin_amdgcn_s_sleep(1);
-#endif
+// A wait on one of the counters (wave-uniform).  The spin is BOUNDED (kTmSpinCap looks at the counter, >= 0.2 s; no wait of
+// the protocol lasts longer than a few march steps): a protocol error must not hang the GPU -- a wait that runs out sets the
+// up-leg's `broken` word, and the up-leg then poisons its result (NaN into x and the norms: the env comes out `diverged`,
+// loudly).  The FORM of the loop matters far beyond its own cycles -- these functions' bodies decide what the compiler may
+// assume around their call sites in the step kernel.  Same memory, per launch against the strip pipeline, 1 env / 256 envs:
+//   this form (counter dead behind the loop, expiry found by looking once more)   -14.0 % /  -8.7 %
+//   the same without the second look (expiry passes silently)                      -14.8 % /  -9.4 %
+//   `if (it == cap) broken = 1` behind the loop                                    -10.9 % /  -6.4 %
+//   `if (it == cap) __builtin_trap()`                                               -7.8 % /  -3.7 %
+//   unbounded `while (word < need) s_sleep`                                         -6.0 % /  +1.2 %
+// (s_sleep 0 instead of 1: no difference.)
+constexpr int kTmSpinCap = 1 << 22;
+__device__ __forceinline__ void tm_wait(const lds_i *w, int need, lds_i *broken) {
+  // (the loop in exactly this form -- its counter dead behind it; the expiry is found by looking at the word once more)
+  for (int it = 0; it < kTmSpinCap && uni(*(volatile const lds_i *)w) < need; ++it) __builtin_amdgcn_s_sleep(AFC_TM_SLEEP);
+  if (uni(*(volatile const lds_i *)w) < need) *(volatile lds_i *)broken = 1;
   asm volatile("" ::: "memory");
 }
-// ---- the helpers' two bodies, written for what they are: one four-column chunk of one row per lane, rows without special
-// cells (fill_load / fill_apply / exit_load / exit_apply -- the generic forms, which the passes that cross a body keep --
-// spend two thirds of their ~200 instructions per chunk on 64-bit lane addresses, boundary selects and per-cell
-// coefficient look-ups).  Same loads, same expressions in the same order: same bits.
-struct TmH {             // wave-uniform unless noted
-  const float *r, *xc;   // the level's residual, the coarse level's x
-  float *x, *rw;         // the level's x (and r, where it is written back)
-  int n, n_, m, mc;
-  float cu, iv0, dg;     // dg = -(((cu + cu) + cu) + cu)
-  unsigned a_rr, a_inv;  // LDS byte addresses: ring slot 0 column 0 of the r ring, invtab[9]
-  bool hasc, need_r, store_r, update_x;
-  // per lane
-  int a, c0;             // chunk of the row; row of the lane's chunk in pass p = ND p + c0
-  bool first, last;      // the chunk at the lower / upper wall
-};
-struct TmFillIn {
-  F4 r, va;
-  float w1, w2, e1, e2;
-};
-template <int CB>
-__device__ __forceinline__ TmFillIn tm_fill_load(const TmH &H, const int g) {
-  TmFillIn in;
-  in.r = ld4b(H.r, 4u * (unsigned)(g * H.m + 1 + 4 * H.a));
-  if (H.hasc) {
-    const int gw = (g - 1 < 1) ? 1 : g - 1, ge = (g + 1 > H.n_) ? H.n_ : g + 1;
-    const unsigned ca = 4u * (unsigned)((((g - 1) >> 1) + 1) * H.mc + 2 * H.a);  // coarse columns 2a .. 2a+3
-    const unsigned cw = 4u * (unsigned)((((gw - 1) >> 1) + 1) * H.mc + 2 * H.a + 1), ce = 4u * (unsigned)((((ge - 1) >> 1) + 1) * H.mc + 2 * H.a + 1);
-    in.va = ld4b(H.xc, ca);
-    float t2[2];
-    __builtin_memcpy(t2, (const char *)H.xc + cw, 8);
-    in.w1 = t2[0], in.w2 = t2[1];
-    __builtin_memcpy(t2, (const char *)H.xc + ce, 8);
-    in.e1 = t2[0], in.e2 = t2[1];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) in.va.v[e] = 0.f;
-    in.w1 = in.w2 = in.e1 = in.e2 = 0.f;
-  }
-  return in;
-}
-// r (after the prolongation increment) and d0 = r * inv of one chunk -> rings (fill_apply's arithmetic, PoissonMatrix.pde:53-64 order)
-template <int CB, bool ZB>
-__device__ __forceinline__ void tm_fill_apply(const TmH &H, const int g, const TmFillIn &in) {
-  constexpr unsigned PWB = TMC<CB>::PW * 4u, RINGB = TMC<CB>::NR * PWB;
-  float lwv = H.cu, lev = H.cu, ls0 = H.cu, ln3 = H.cu, ivm = H.iv0, ivf = H.iv0, ivl = H.iv0;
-  if (ZB) {  // zeroed boundary faces (coarse levels): the wall chunks and the first / last row know them
-    lwv = (g == 1) ? 0.f : H.cu;
-    lev = (g == H.n_) ? 0.f : H.cu;
-    ls0 = H.first ? 0.f : H.cu;
-    ln3 = H.last ? 0.f : H.cu;
-    const unsigned at = H.a_inv + ((g == 1) ? 12u : ((g == H.n_) ? 24u : 0u));
-    ivm = *(const lds_f *)(uintptr_t)at;
-    ivf = H.first ? *(const lds_f *)(uintptr_t)(at + 4u) : ivm;
-    ivl = H.last ? *(const lds_f *)(uintptr_t)(at + 8u) : ivm;
-  }
-  // (scalar on purpose: as packed f32 pairs the same arithmetic issued MORE instructions -- the pairs have to be assembled --
-  // and took a third longer at 1024 workgroups; measured, tools/upleg_bench.hip)
-  F4 rv = in.r, dv;
-  if (H.hasc) {
-    const float a1 = in.va.v[1], a2 = in.va.v[2];
-    const float a0 = H.first ? a1 : in.va.v[0], a3 = H.last ? a2 : in.va.v[3];
-    const float dc[4] = {a1, a1, a2, a2}, dw[4] = {in.w1, in.w1, in.w2, in.w2}, de[4] = {in.e1, in.e1, in.e2, in.e2};
-    const float ds[4] = {a0, a1, a1, a2}, dn[4] = {a1, a2, a2, a3};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lsv = (e == 0) ? ls0 : H.cu, lnv = (e == 3) ? ln3 : H.cu;
-      const float diag = ZB ? -(lwv + lev + lsv + lnv) : H.dg;
-      rv.v[e] = rv.v[e] - (dc[e] * diag + dw[e] * lwv + de[e] * lev + ds[e] * lsv + dn[e] * lnv);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) dv.v[e] = rv.v[e] * ((e == 0) ? ivf : ((e == 3) ? ivl : ivm));  // MG.pde:80
-  const unsigned sl = H.a_rr + (unsigned)(g % TMC<CB>::NR) * PWB + 4u * (unsigned)(1 + 4 * H.a);
-  f4a r4, d4;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) r4[e] = rv.v[e], d4[e] = dv.v[e];
-  *(lds_f4 *)(uintptr_t)sl = r4;
-  *(lds_f4 *)(uintptr_t)(sl + RINGB) = d4;
-}
-struct TmExitIn {
-  F4 x;
-  float a1, a2, gl, gh;
-};
-template <int CB>
-__device__ __forceinline__ TmExitIn tm_exit_load(const TmH &H, const int g) {
-  TmExitIn in;
-  in.a1 = in.a2 = in.gl = in.gh = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) in.x.v[e] = 0.f;
-  if (!H.update_x) return in;
-  const unsigned kb = 4u * (unsigned)(g * H.m + 1 + 4 * H.a);
-  in.x = ld4b(H.x, kb);
-  if (H.hasc) {
-    float t2[2];
-    __builtin_memcpy(t2, (const char *)H.xc + 4u * (unsigned)((((g - 1) >> 1) + 1) * H.mc + 2 * H.a + 1), 8);
-    in.a1 = t2[0], in.a2 = t2[1];
-  }
-  if (H.first) in.gl = ld1b(H.x, kb - 4u);
-  if (H.last) in.gh = ld1b(H.x, kb + 16u);
-  return in;
-}
-// d.setBC(); x += d (+ the ghosts that mirror the chunk); r -= A d (exit_apply's arithmetic, MG.pde:90-97)
-template <int CB, bool ZB>
-__device__ __forceinline__ void tm_exit_apply(const TmH &H, const int g, const TmExitIn &in, double &rr_part, double &xs_part,
-                                              float &linf) {
-  constexpr int NR = TMC<CB>::NR;
-  constexpr unsigned PWB = TMC<CB>::PW * 4u, RINGB = NR * PWB;
-  const unsigned kb = 4u * (unsigned)(g * H.m + 1 + 4 * H.a);
-  const int sg = g % NR;
-  const unsigned colb = 4u * (unsigned)(1 + 4 * H.a);
-  const unsigned sl = H.a_rr + (unsigned)sg * PWB + colb;  // row g of the r ring; the d ring is RINGB further
-  float dp[4] = {0.f, 0.f, 0.f, 0.f};
-  if (H.hasc) dp[0] = dp[1] = in.a1, dp[2] = dp[3] = in.a2;
-  const f4a dc4 = *(const lds_f4 *)(uintptr_t)(sl + RINGB);
-  float d6[6];  // d at columns j-1 .. j+4 with the setBC mirror
-  d6[0] = *(const lds_f *)(uintptr_t)(sl + RINGB - 4u);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) d6[1 + e] = dc4[e];
-  d6[5] = *(const lds_f *)(uintptr_t)(sl + RINGB + 16u);
-  if (H.first) d6[0] = d6[1];
-  if (H.last) d6[5] = d6[4];
-  if (H.need_r) {
-    // rows g-1, g+1 (clamped to the grid: d.setBC mirrors the first / last row into the ghost rows)
-    const int sw = (g == 1) ? sg : (sg == 0 ? NR - 1 : sg - 1), se = (g == H.n_) ? sg : (sg == NR - 1 ? 0 : sg + 1);
-    const f4a w4 = *(const lds_f4 *)(uintptr_t)(H.a_rr + RINGB + (unsigned)sw * PWB + colb);
-    const f4a e4 = *(const lds_f4 *)(uintptr_t)(H.a_rr + RINGB + (unsigned)se * PWB + colb);
-    const f4a o4 = *(const lds_f4 *)(uintptr_t)sl;
-    float lwv = H.cu, lev = H.cu, ls0 = H.cu, ln3 = H.cu;
-    if (ZB) {
-      lwv = (g == 1) ? 0.f : H.cu;
-      lev = (g == H.n_) ? 0.f : H.cu;
-      ls0 = H.first ? 0.f : H.cu;
-      ln3 = H.last ? 0.f : H.cu;
-    }
-    F4 rn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lsv = (e == 0) ? ls0 : H.cu, lnv = (e == 3) ? ln3 : H.cu;
-      const float diag = ZB ? -(lwv + lev + lsv + lnv) : H.dg;
-      const float d = d6[1 + e];
-      rn.v[e] = o4[e] - (d * diag + w4[e] * lwv + e4[e] * lev + d6[e] * lsv + d6[2 + e] * lnv);
-      const float pr = rn.v[e] * rn.v[e];
-      rr_part += (double)pr;
-      linf = jmax(linf, jabs(rn.v[e]));
-    }
-    if (H.store_r) st4b(H.rw, kb, rn);
-  }
-  if (!H.update_x) return;
-  F4 xn;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float xo = in.x.v[e];
-    if (H.hasc) xo = xo + dp[e];
-    xn.v[e] = xo + d6[1 + e];
-    if (H.need_r) xs_part += (double)xn.v[e];
-  }
-  st4b(H.x, kb, xn);
-  // ghosts mirror the adjacent interior cell (d.setBC(), Field.pde:211-224)
-  if (H.first) {
-    float xg = in.gl;
-    if (H.hasc) xg = xg + dp[0];
-    st1b(H.x, kb - 4u, xg + d6[1]);
-  }
-  if (H.last) {
-    float xg = in.gh;
-    if (H.hasc) xg = xg + dp[3];
-    st1b(H.x, kb + 16u, xg + d6[4]);
-  }
-  if (g == 1 || g == H.n_) {
-    const unsigned kg = 4u * (unsigned)(((g == 1) ? 0 : (H.n - 1)) * H.m + 1 + 4 * H.a);
-    const F4 xg4 = ld4b(H.x, kg);
-    F4 xgn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float xg = xg4.v[e];
-      if (H.hasc) xg = xg + dp[e];
-      xgn.v[e] = xg + d6[1 + e];
-    }
-    st4b(H.x, kg, xgn);
-    if (H.first) {
-      float xg = ld1b(H.x, kg - 4u);
-      if (H.hasc) xg = xg + dp[0];
-      st1b(H.x, kg - 4u, xg + d6[1]);
-    }
-    if (H.last) {
-      float xg = ld1b(H.x, kg + 16u);
-      if (H.hasc) xg = xg + dp[3];
-      st1b(H.x, kg + 16u, xg + d6[4]);
-    }
-  }
-}
-
 // What the march needs from its caller (everything wave-uniform but `lane`): passed by value to a function of its own.
 struct TmArgs {
   int n_, Dmax, has_sp, sp_i0, sp_i1, sb0, sb1, TW, TR, tc0;
   float cu, it0, it1, it2;
-  unsigned a_rr, a_z, a_tab, a_apk, a_cF, a_cM;
+  unsigned a_rr, a_z, a_tab, a_apk, a_cF, a_cM, a_cB;
 };
 // The march as a function of its own (one call per level and up-leg): inlined into the step kernels its ~90 live
 // registers compete with everything that is live across the call site, and the allocator answers with scratch reloads
@@ -468,6 +281,7 @@ __device__ __noinline__ void tm_march(const TmArgs A_) {
   const bool has_sp = uni(A_.has_sp) != 0;
   const int sp_i0 = uni(A_.sp_i0), sp_i1 = uni(A_.sp_i1), sb0 = uni(A_.sb0), sb1 = uni(A_.sb1);
   const lds_i *cF = (const lds_i *)(uintptr_t)uni((int)A_.a_cF);
+  lds_i *cB = (lds_i *)(uintptr_t)uni((int)A_.a_cB);
   TmState<CB> S;
   {
     const unsigned colb = 4u * (unsigned)(1 + CB * c);  // byte offset of the lane's first column in a ring row
@@ -516,7 +330,7 @@ __device__ __noinline__ void tm_march(const TmArgs A_) {
       need = need > Dmax ? Dmax : need;                                                                        \
       if (uni(fv) < need) {                                                                                    \
         TM_WAIT_PROF_BEGIN                                                                                     \
-        tm_wait(cF, need);                                                                                     \
+        tm_wait(cF, need, cB);                                                                                 \
         TM_WAIT_PROF_END                                                                                       \
       }                                                                                                        \
     }                                                                                                          \
@@ -541,7 +355,7 @@ __device__ __noinline__ void tm_march(const TmArgs A_) {
 #define TM_WAIT_PROF_BEGIN
 #define TM_WAIT_PROF_END
 #endif
-  tm_wait(cF, 3 > Dmax ? Dmax : 3);
+  tm_wait(cF, 3 > Dmax ? Dmax : 3, cB);
   tm_fetch<CB, true>(S, Q, S.i, S.oa, S.ob, true);  // prime: what step 0 works on
   int T = 0;
   // (T + 2 in the fast test: the second fetch of an iteration is for step T + 2)
@@ -614,9 +428,9 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
   for (int q = tid; q < PW; q += kThreads) zrow[q] = 0.f;
   if (tid < 2 * NR) dr[(tid >> 1) * PW + ((tid & 1) ? m_ + 1 : 0)] = 0.f;  // ghost columns of d read as zero (nobody writes them again)
 #ifdef AFC_TM_EXP_SOLO
-  if (tid < 2 + 64) cnt[tid] = (tid == 0) ? (1 << 20) : 0;  // everything "filled": the march alone (timing experiment, wrong data)
+  if (tid < 2 + 64 + 1) cnt[tid] = (tid == 0) ? (1 << 20) : 0;  // everything "filled": the march alone (timing experiment, wrong data)
 #else
-  if (tid < 2 + 64) cnt[tid] = 0;
+  if (tid < 2 + 64 + 1) cnt[tid] = 0;
 #endif
   if (tid < 2 * CB + 4) apk[tid] = (tid < CB + 4) ? du.cu : du.iv0;
   if (tid >= 64 && tid < 64 + 9) apk[2 * CB + 4 + tid - 64] = D.invtab[tid - 64];
@@ -632,7 +446,7 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
   }
   lds_barrier();
   TM_STAMP(1);
-  lds_i *cF = cnt, *cX = cnt + 1, *cM = cnt + 2;
+  lds_i *cF = cnt, *cX = cnt + 1, *cM = cnt + 2, *cB = cnt + 66;  // F, X | M: one word per lane of the march | broken
   if (tid < 64) {
     // ------------------------------------------------ the march ------------------------------------------------
     TmArgs A_;
@@ -641,6 +455,7 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     A_.cu = du.cu, A_.it0 = uni(D.invtab[0]), A_.it1 = uni(D.invtab[1]), A_.it2 = uni(D.invtab[2]);
     A_.a_rr = lds_addr(rr), A_.a_z = lds_addr(zrow), A_.a_tab = lds_addr(tab), A_.a_apk = lds_addr(apk);
     A_.a_cF = lds_addr((const float *)(lds_f *)cF), A_.a_cM = lds_addr((const float *)(lds_f *)cM);
+    A_.a_cB = lds_addr((const float *)(lds_f *)cB);
     __builtin_amdgcn_s_setprio(3);
     if (du.zb)
       tm_march<CB, true>(A_);
@@ -676,7 +491,8 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     H.r = F.r, H.xc = Cc.x, H.x = F.x, H.rw = F.r;
     H.n = n, H.n_ = n_, H.m = m, H.mc = mc;
     H.cu = du.cu, H.iv0 = du.iv0, H.dg = -(du.cu + du.cu + du.cu + du.cu);
-    H.a_rr = lds_addr(rr) - 4u * 0u, H.a_inv = lds_addr(apk) + 4u * (2 * CB + 4);
+    H.a_rr = lds_addr(rr), H.a_inv = lds_addr(apk) + 4u * (2 * CB + 4);
+    H.pwb = PWB, H.dofs = RINGB;
     H.hasc = HASC, H.need_r = need_r, H.store_r = U.store_r, H.update_x = U.update_x;
     H.a = a, H.c0 = 1 + dd - clo;
     H.first = (a == 0), H.last = (a == CPD - 1);
@@ -684,14 +500,14 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     if (hw == 0) {
       auto issue = [&](const int pq, TmFillIn &fin) {
         const int gf = ND * pq + H.c0;  // row of this lane's chunk (diagonal - column block)
-        if ((pq < npass) && gf >= 1 && gf <= n_) fin = tm_fill_load<CB>(H, gf);
+        if ((pq < npass) && gf >= 1 && gf <= n_) fin = tm_fill_load(H, gf);
       };
       auto work = [&](const int pq, const TmFillIn &fin) {
         const int gf = ND * pq + H.c0;
         const bool fi_on = gf >= 1 && gf <= n_;
         const bool sp_fill = (ND * pq + ND + 1 >= du.sp_i0) && (ND * pq + 1 - 16 <= du.sp_i1);  // rows of a pass: first diagonal - 15 .. last diagonal
         const int needx = ND * pq + ND - NR + 1;
-        if (needx > 0) tm_wait(cX, needx > Dmax ? Dmax : needx);
+        if (needx > 0) tm_wait(cX, needx > Dmax ? Dmax : needx, cB);
 #ifdef AFC_TM_EXP_NOAPPLY
         if (fi_on && n_ < 0) {
 #else
@@ -705,9 +521,9 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
             gi.w1 = fin.w1, gi.w2 = fin.w2, gi.e1 = fin.e1, gi.e2 = fin.e2;
             fill_apply(U, HASC, gf, a, gi, true);
           } else if (zb)
-            tm_fill_apply<CB, true>(H, gf, fin);
+            tm_fill_apply<NR, true>(H, gf, fin);
           else
-            tm_fill_apply<CB, false>(H, gf, fin);
+            tm_fill_apply<NR, false>(H, gf, fin);
         }
         const int v = ND * pq + ND;
         pipe_post_word(cF, v > Dmax ? Dmax : v);
@@ -726,7 +542,7 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     } else {
       auto issue = [&](const int pe, TmExitIn &ein) {
         const int ge = ND * pe + H.c0;
-        if ((pe < npass) && ge >= 1 && ge <= n_) ein = tm_exit_load<CB>(H, ge);
+        if ((pe < npass) && ge >= 1 && ge <= n_) ein = tm_exit_load(H, ge);
       };
       auto work = [&](const int pe, const TmExitIn &ein) {
         const int ge = ND * pe + H.c0;
@@ -734,7 +550,7 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
         const bool sp_exit = (ND * pe + ND + 1 >= du.sp_i0) && (ND * pe + 1 - 16 <= du.sp_i1);
         int needm = ND * pe + ND + KX;
         needm = needm > n_ + K::SPAN + 2 ? n_ + K::SPAN + 2 : needm;
-        tm_wait(cM, needm);
+        tm_wait(cM, needm, cB);
 #ifdef AFC_TM_EXP_NOAPPLY
         if (ex_on && n_ < 0) {
 #else
@@ -745,11 +561,11 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
             gi.x = ein.x, gi.a1 = ein.a1, gi.a2 = ein.a2, gi.gl = ein.gl, gi.gh = ein.gh;
             exit_apply(U, HASC, need_r, ge, a, gi, true, rr_part, xs_part, linf);
           } else if (zb)
-            tm_exit_apply<CB, true>(H, ge, ein, rr_part, xs_part, linf);
+            tm_exit_apply<NR, true>(H, ge, ein, rr_part, xs_part, linf);
           else
-            tm_exit_apply<CB, false>(H, ge, ein, rr_part, xs_part, linf);
+            tm_exit_apply<NR, false>(H, ge, ein, rr_part, xs_part, linf);
         }
-        tm_wait(cX, ND * pe);  // in order
+        tm_wait(cX, ND * pe, cB);  // in order
         const int v = ND * pe + ND;
         pipe_post_word(cX, v > Dmax ? Dmax : v);
       };
@@ -771,6 +587,7 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
   if (tid == 128) TM_STAMP(6);
   __syncthreads();  // phase boundary: the x (and r) this level stored must be visible to what follows
   TM_STAMP(4);
+  const bool broken = uni(*(volatile const lds_i *)cB) != 0;  // a wait of the hand-over protocol ran out: never seen; must not pass silently
   TrOut o;
   o.rr = o.linf = o.xs = 0.f;
   if (need_r && rmode != 2) {
@@ -778,6 +595,11 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     o.rr = uni((float)rr_part);
     o.linf = uni(linf);
     o.xs = uni((float)xs_part);
+  }
+  if (broken) {
+    const float qnan = __builtin_nanf("");
+    o.rr = o.linf = o.xs = qnan;
+    if (tid == 0) F.x[m + 1] = qnan;  // the level's first interior cell: the NaN reaches p and the force, the env reports `diverged`
   }
   return o;
 }

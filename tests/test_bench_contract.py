@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r5_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r6_bench.json")) as f:
         return json.loads(f.read().strip().split("\n")[-1])
 
 
@@ -82,12 +82,12 @@ def test_committed_traffic_figure_belongs_to_the_shipped_kernel_sources():
 def test_other_baseline_configs_are_named_not_custom():
     """the secondary workloads are lines of driver grade too: named, with cpu_baseline and (where the committed PMC
     figure belongs to the same kernel sources) roofline.traffic, >= 64 timed agent steps"""
-    for f, name in (("r5_bench_cfg4.json", "BASELINE.json configs[3]"), ("r5_bench_native.json", "reference-native 384x192")):
+    for f, name in (("r6_bench_cfg4.json", "BASELINE.json configs[3]"), ("r6_bench_native.json", "reference-native 384x192")):
         with open(os.path.join(ROOT, "profiles", f)) as fh:
             d = json.loads(fh.read().strip().split("\n")[-1])
         assert d["config"]["workload"].startswith(name) and d["roofline"]["frac"] > 0.35 and d["diverged_envs"] == 0
         assert d["steps"] >= 64 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
         assert d["roofline"]["traffic"] is None or 1.0 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.5
-    with open(os.path.join(ROOT, "profiles", "r5_bench_perfmode.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r6_bench_perfmode.json")) as fh:
         d = json.loads(fh.read().strip().split("\n")[-1])
     assert "PERF MODE" in d["config"]["workload"] and d["config"]["gs_order"].startswith("red-black")

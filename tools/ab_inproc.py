@@ -45,11 +45,16 @@ def main():
     stream = torch.cuda.current_stream()
     envs = []
     for k, lib in enumerate(a.libs):
-        # "lib.so:VAR=value,VAR2=value" sets environment variables while this library's env is created (allocation experiments)
+        # "lib.so:VAR=value,VAR2=value" sets environment variables while this library's env is created (allocation
+        # experiments); lower-case names are afc_config fields instead ("lib.so:upleg=3")
         lib, _, evs = lib.partition(":")
         a.libs[k] = lib + (":" + evs if evs else "")
+        cfg_over = {}
         for kv in filter(None, evs.split(",")):
-            os.environ[kv.split("=")[0]] = kv.split("=")[1]
+            if kv.split("=")[0].islower():
+                cfg_over[kv.split("=")[0]] = int(kv.split("=")[1])
+            else:
+                os.environ[kv.split("=")[0]] = kv.split("=")[1]
         if a.share_slab and k == 0:
             os.environ["AFC_EXPORT_SLAB"] = "1"
         if a.share_slab and k > 0:
@@ -58,14 +63,15 @@ def main():
             libc.getenv.restype = ctypes.c_char_p
             os.environ["AFC_SLAB_PTR"] = libc.getenv(b"AFC_LAST_SLAB").decode()
         m = load_env_module(str(k), lib)
-        g = m.AFCEnv(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, device=0)
+        g = m.AFCEnv(num_envs=a.envs, resolution=a.res, reynolds=a.reynolds, device=0, **cfg_over)
         os.environ.pop("AFC_SLAB_PTR", None)
         if z is not None and z["u"].shape == (g.n, g.m):
             g.set_reset_state(z["u"], z["v"], z["p"])
         g.use_device_io(stream.cuda_stream)
         envs.append(g)
         for kv in filter(None, evs.split(",")):
-            os.environ.pop(kv.split("=")[0], None)
+            if not kv.split("=")[0].islower():
+                os.environ.pop(kv.split("=")[0], None)
     E = a.envs
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ on a GPU box (run through gpurun from the repo root):
-#   tools/refresh_profiles.sh <tag>      e.g. r5   -> gpurun_out/profiles_<tag>/
+#   tools/refresh_profiles.sh <tag>      e.g. r6   -> gpurun_out/profiles_<tag>/
 # For each of the three measured grids (BASELINE configs[1] 256x128, configs[3] 512x256, reference-native 384x192): the
 # bench line with cpu_baseline and roofline.traffic (HBM bytes per launch from two PMC passes on the same sources), and the
 # lock-step phase times.  For the headline grid also: rocprofv3 kernel stats, steady launch average, SQ / LDS counters,
 # per-phase counters and traffic, per-level profile, the perf-mode line with its counters, the march micro-benchmark and
 # the memory-placement evidence (tools/ab_inproc.py).
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -48,9 +48,9 @@ for g in "16 " "32 _cfg4" "24 _native"; do
   set -- $g
   timeout 400 python tools/phase_times.py 1024 $1 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1024$2.txt
 done
-timeout 300 python tools/phase_times.py 1 16 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1.txt
+UPLEG=1 timeout 300 python tools/phase_times.py 1 16 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1.txt
 timeout 300 python tools/level_profile.py 1024 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1024.txt
-timeout 300 python tools/level_profile.py 1 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1.txt
+UPLEG=1 timeout 300 python tools/level_profile.py 1 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1.txt
 rm -rf $O/stats $O/pmc_f* $O/pmc_w* $O/pmc_sq $O/pmc_sq2 $O/pmc_perf $O/pt_f* $O/pt_w*
 bash tools/phase_counters.sh $O/phase_counters > /dev/null 2>&1
 cat $O/phase_counters/p1.txt $O/phase_counters/p2.txt $O/phase_counters/p3.txt > $O/${TAG}_phase_counters.txt
@@ -61,9 +61,19 @@ L=rlfluidcontrol_amd/libafc_env.so
 (echo "AFC_PLACEMENT_TRIALS=1 (first allocation taken), six instances of one process:"; python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 $L:AFC_PLACEMENT_TRIALS=1 2>&1 | grep "ms per launch";
  echo "default (best of 16 to 32 candidate allocations by the streaming probe), three instances of one process:"; AFC_PRINT_ALLOC=1 python tools/ab_inproc.py --blocks 6 --per-block 6 --action-scale 0 $L $L $L 2>&1 | grep "ms per launch\|candidate") > $O/${TAG}_placement.txt
 (cd tools; for kp in 36 42; do for nw in 1 2 4; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DAFC_ONLY_MODE=0 -DNW=$nw -DAFC_KPAD_FORCE=$kp march_bench.hip -o /tmp/mb 2>/dev/null && echo "pitch pad $kp, marching waves per workgroup $nw" && /tmp/mb 0 | grep -v "workgroups=   1"; done; done) > $O/${TAG}_march_bench.txt 2>&1
-# ---- round 5: launch time against the number of envs (1 .. 4 workgroups per CU), the up-leg alone, the placement probe ----
-(for E in 1 256 512 768 1024; do python tools/ab_inproc.py --envs $E --blocks 4 --per-block 4 $L 2>&1 | grep "ms per launch" | sed "s/^/E=$E  /"; done) > $O/${TAG}_launch_time_by_envs.txt
-(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -o /tmp/ub tools/upleg_bench.hip 2>/dev/null && for a in "128 0 1 1" "64 1 0 0" "32 1 0 0"; do /tmp/ub $a; done) > $O/${TAG}_upleg_bench.txt 2>&1
+# ---- launch time against the number of envs (1 env .. 4 workgroups per CU): what ships (afc_config.upleg = 0: the march
+# down the rows below 2.5 envs per CU, the strip pipeline above) and the two up-legs forced, on the SAME memory when a
+# -DAFC_DEVHOOKS=1 build of these sources is there (tools/build_variant.sh r6, built before the gpurun call) ----
+V=tools/bin/libafc_r6.so
+if [ -f $V ]; then SH="--share-slab"; else V=$L; SH=""; fi
+(for E in 1 64 256 512 640 768 1024; do python tools/ab_inproc.py $SH --envs $E --blocks 4 --per-block 4 $V:upleg=1 $V:upleg=3 $V 2>&1 | grep "ms per launch" | sed "s/^/E=$E  /"; done) > $O/${TAG}_launch_time_by_envs.txt
+# ---- one level's up-leg in isolation: barrier form | strip pipeline | march down the rows, bits and time; rows that cross a body ----
+(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -Wno-unused-function -Iinclude -DAFC_TM_PROF=1 -o /tmp/ub tools/upleg_bench.hip 2>/dev/null && for a in "128 0 1 1 1" "64 1 0 0 1" "32 1 0 0 1"; do /tmp/ub $a; done) > $O/${TAG}_upleg_bench.txt 2>&1
+# ---- bench lines of a small batch (256 envs = one per CU): what ships there (the march down the rows) and the strip pipeline ----
+timeout 300 python bench.py --no-cpu-baseline --envs 256 > $O/${TAG}_bench_256envs.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --envs 256 --upleg 1 > $O/${TAG}_bench_256envs_strip_pipeline.json 2>> $O/bench.err
+UPLEG=3 timeout 300 python tools/phase_times.py 1 16 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_times_E1_rows_march.txt
+UPLEG=3 timeout 300 python tools/level_profile.py 1 8 2>&1 | grep -v amdgpu.ids > $O/${TAG}_level_profile_E1_rows_march.txt
 (/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value -o /tmp/vp tools/vmm_probe.hip 2>/dev/null && /tmp/vp 1740 10) > $O/${TAG}_vmm_placement_probe.txt 2>&1
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do python bench.py --no-cpu-baseline --steps 8 --repeats 2 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['copy_ceiling_measured_GBs'])"; done > $O/${TAG}_placement_reliability.txt
 tail -1 $O/${TAG}_bench.json | cut -c1-400; cat $O/${TAG}_steady_launch.txt $O/${TAG}_hbm_traffic.json $O/${TAG}_phase_traffic.txt

@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256, 4) void k(Args A) {
       mg_up_smooth<16>(true, Fu, Cu, A.need_r != 0, lds, nullptr, &rr, &linf, pf, &xs, A.rmode);
     else if (MODE == 1)
       mg_up_pipe(true, Fu, Cu, A.need_r != 0, lds, nullptr, &rr, &linf, pf, &xs, A.rmode);
-    else
-      up_tr(true, Fu, Cu, A.need_r != 0, lds, &rr, &linf, pf, &xs, A.rmode);
+    else {
+      afc::lat::ProfT pfl;
+      afc::lat::up_tr(true, Fu, Cu, A.need_r != 0, lds, &rr, &linf, pfl, &xs, A.rmode);
+    }
   }
   t0 = wall_clock64() - t0;
   if (threadIdx.x == 0) {
@@ -155,7 +157,7 @@ int main(int argc, char **argv) {
         else {
 #ifdef AFC_TM_PROF
           long long z[64] = {0};
-          hipMemcpyToSymbol(HIP_SYMBOL(afc::prod::g_tm_prof), z, sizeof(z));
+          hipMemcpyToSymbol(HIP_SYMBOL(afc::lat::g_tm_prof), z, sizeof(z));
 #endif
           k<2><<<wg, 256, lds_bytes>>>(A);
         }
@@ -199,7 +201,7 @@ int main(int argc, char **argv) {
 #ifdef AFC_TM_PROF
   {
     long long hp[64];
-    hipMemcpyFromSymbol(hp, HIP_SYMBOL(afc::prod::g_tm_prof), sizeof(hp));
+    hipMemcpyFromSymbol(hp, HIP_SYMBOL(afc::lat::g_tm_prof), sizeof(hp));
     printf("prof (cycles, last launch, workgroup 0, last call): init %lld | to march loop %lld | march loop %lld | march end -> barrier %lld | fill wave end %lld | exit wave end %lld (after march start) | waited %lld cycles in %lld waits (all calls)\n",
            hp[1] - hp[0], hp[2] - hp[1], hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[2], hp[6] - hp[2], hp[8], hp[9]);
   }

@@ -1,7 +1,9 @@
 #!/bin/bash
-# SQ counters of the isolated up-leg kernels at 1024 workgroups: mg_up_smooth (k<0>), mg_up_pipe (k<1>), mg_up_tr (k<2>)
+# tools/upleg_counters.sh: SQ counters of the isolated up-leg kernels of tools/upleg_bench.hip at 1024 workgroups (four per CU, all
+# in the same phase): mg_up_smooth (k<0>), mg_up_pipe (k<1>), mg_up_tr (k<2>) -- per workgroup and launch of 8 calls.  GPU box, from the
+# repo root, with tools/bin/upleg_bench built (see the head of tools/upleg_bench.hip).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r6/ctr
+O=$R/gpurun_out/upleg_ctr
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $O/p1 -- $R/tools/bin/upleg_bench 128 0 1 1 1 1024 > $O/p1.log 2>&1
@@ -10,7 +12,7 @@ cd $R
 python3 - <<'PY'
 import csv,glob,collections
 for p in ("p1","p2"):
-    files=glob.glob("gpurun_out/r6/ctr/%s/**/*counter_collection.csv"%p, recursive=True)
+    files=glob.glob("gpurun_out/upleg_ctr/%s/**/*counter_collection.csv"%p, recursive=True)
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for row in csv.DictReader(open(f)):
