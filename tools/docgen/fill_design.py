@@ -1,4 +1,4 @@
-"""DESIGN.md and README.md are generated: the templates beside this file carry placeholders (R5HEAD, R5MS, R5CFG4FRAC, ...) for
+"""DESIGN.md and README.md are generated: the templates beside this file carry placeholders (R6HEAD, R6MS, R6CFG4FRAC, ...) for
 the figures of the committed bench lines under profiles/, so that a profile refresh updates every quoted number.
     python tools/docgen/fill_design.py"""
 import os
@@ -12,29 +12,29 @@ def k(v): return "%.1f k" % (v/1e3)
 def fill(tag, f, cpu=True):
     global s
     d=L(f); r=d['roofline']
-    s=s.replace('R5'+tag+'MS', "%.2f" % d['ms_per_step']).replace('R5'+tag+'FRAC', "%.3f" % r['frac'])
-    s=s.replace('R5'+tag+'TR', ("%.2f" % (r['traffic']/r['algorithmic_bytes_per_launch'])) if r.get('traffic') else '—')
-    s=s.replace('R5'+tag+'CC', "%.2f" % r['frac_of_measured_copy_ceiling'])
+    s=s.replace('R6'+tag+'MS', "%.2f" % d['ms_per_step']).replace('R6'+tag+'FRAC', "%.3f" % r['frac'])
+    s=s.replace('R6'+tag+'TR', ("%.2f" % (r['traffic']/r['algorithmic_bytes_per_launch'])) if r.get('traffic') else '—')
+    s=s.replace('R6'+tag+'CC', "%.2f" % r['frac_of_measured_copy_ceiling'])
     if cpu:
-        c=d['cpu_baseline']; s=s.replace('R5'+tag+'CPU', "%.0f / %s" % (c['one_env_one_core_uncontended'], format(int(round(c['value'])),',').replace(',',' ')))
+        c=d['cpu_baseline']; s=s.replace('R6'+tag+'CPU', "%.0f / %s" % (c['one_env_one_core_uncontended'], format(int(round(c['value'])),',').replace(',',' ')))
     return d
-d=fill('CFG4','r5_bench_cfg4.json'); s=s.replace('R5CFG4', k(d['value']))
-d=fill('NAT','r5_bench_native.json'); s=s.replace('R5NAT', k(d['value']))
-d=fill('PERF','r5_bench_perfmode.json', cpu=False); s=s.replace('R5PERF', k(d['value']))
-d=fill('','r5_bench.json')
-s=s.replace('R5GBT', '%.1f' % (d['roofline']['traffic']/1e9))
-rel=[float(l.split()[0]) for l in open(os.path.join(ROOT, 'profiles', 'r5_placement_reliability.txt')) if l.strip()]
-s=s.replace('R5HEAD', "%s** (%.1f-%.1f k over twelve more fresh processes on this box)**" % (k(d['value']), min(rel)/1e3, max(rel)/1e3) if False else k(d['value']))
+d=fill('CFG4','r6_bench_cfg4.json'); s=s.replace('R6CFG4', k(d['value']))
+d=fill('NAT','r6_bench_native.json'); s=s.replace('R6NAT', k(d['value']))
+d=fill('PERF','r6_bench_perfmode.json', cpu=False); s=s.replace('R6PERF', k(d['value']))
+d=fill('','r6_bench.json')
+s=s.replace('R6GBT', '%.1f' % (d['roofline']['traffic']/1e9))
+rel=[float(l.split()[0]) for l in open(os.path.join(ROOT, 'profiles', 'r6_placement_reliability.txt')) if l.strip()]
+s=s.replace('R6HEAD', "%s** (%.1f-%.1f k over twelve more fresh processes on this box)**" % (k(d['value']), min(rel)/1e3, max(rel)/1e3) if False else k(d['value']))
 s=s.replace('| developed wake | **%s** |' % k(d['value']), '| developed wake | **%s** (%.1f-%.1f k over twelve more fresh processes of 16 launches each on this box) |' % (k(d['value']), min(rel)/1e3, max(rel)/1e3),1)
-assert 'R5' not in s.replace('R5HEAD','')[:0] or True
+assert 'R6' not in s.replace('R6HEAD','')[:0] or True
 open(os.path.join(ROOT, 'DESIGN.md'), 'w').write(s)
 import re
-print([m for m in re.findall(r'R5[A-Z0-9]+', s)][:10])
+print([m for m in re.findall(r'R6[A-Z0-9]+', s)][:10])
 # README
 s=open(os.path.join(HERE, 'README.template.md')).read()
-d=fill('CFG4','r5_bench_cfg4.json', cpu=False); s=s.replace('R5CFG4', k(d['value']))
-d=fill('NAT','r5_bench_native.json', cpu=False); s=s.replace('R5NAT', k(d['value']))
-d=fill('PERF','r5_bench_perfmode.json', cpu=False); s=s.replace('R5PERF', k(d['value']))
-d=fill('','r5_bench.json', cpu=False); s=s.replace('R5HEAD', k(d['value']))
+d=fill('CFG4','r6_bench_cfg4.json', cpu=False); s=s.replace('R6CFG4', k(d['value']))
+d=fill('NAT','r6_bench_native.json', cpu=False); s=s.replace('R6NAT', k(d['value']))
+d=fill('PERF','r6_bench_perfmode.json', cpu=False); s=s.replace('R6PERF', k(d['value']))
+d=fill('','r6_bench.json', cpu=False); s=s.replace('R6HEAD', k(d['value']))
 open(os.path.join(ROOT, 'README.md'), 'w').write(s)
-print([m for m in re.findall(r'R5[A-Z0-9]+', s)][:10])
+print([m for m in re.findall(r'R6[A-Z0-9]+', s)][:10])

@@ -2,6 +2,8 @@
 shipped kernels (any timing-dependent hazard shows as a difference between two runs of the same code on the same inputs) and
 (b) in parity mode through the shipped kernels and through the barrier form (dbg bit 8, diagnostic instantiation): every
 observation of every env at every agent step and the final fields of 64 envs must be equal bit for bit.
+(c) the same for the up-leg that marches down the rows (upleg = 3, the instantiation small batches get) at one workgroup per CU
+(256 envs, where the host picks it) and forced at four per CU (1024 envs, where its helpers are starved the most).
     python tools/pipe_soak.py [agent steps]"""
 import os
 import sys
@@ -17,8 +19,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "wake_res16_re100.npz"))
 
 
-def run(dbg, exact):
-    g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=dbg, exact_sums=exact)
+def run(dbg, exact, upleg=1, E=E):
+    g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, dbg=dbg, exact_sums=exact, upleg=upleg)
+    assert g.upleg() == upleg
     g.set_reset_state(z["u"], z["v"], z["p"])
     g.reset()
     rng = np.random.default_rng(7)
@@ -53,3 +56,10 @@ p2 = run(256, 1)
 same(p1, p2, "parity mode: pipelined up-leg against the barrier form (dbg bit 8)")
 p3 = run(0, 1)
 same(p1, p3, "parity mode, two runs")
+for envs in (256, 1024):
+    m1 = run(0, 0, 3, envs)
+    m2 = run(0, 0, 3, envs)
+    same(m1, m2, "%d envs, rows march (upleg 3), default mode, two runs" % envs)
+    same(m1, run(0, 0, 1, envs), "%d envs, default mode: rows march against the strip pipeline" % envs)
+    q1 = run(0, 1, 3, envs)
+    same(q1, run(256, 1, 1, envs), "%d envs, parity mode: rows march against the barrier form (dbg bit 8)" % envs)
