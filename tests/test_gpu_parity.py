@@ -182,8 +182,9 @@ def test_mg_solver_vs_oracle(envmod, oracle_mod, res, Re, impl):
     g.close()
 
 
-def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0, impl=2, fuse_tail=0):
-    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact, impl=impl, fuse_tail=fuse_tail)
+def _run_pair(envmod, oracle_mod, res, Re, nsteps, actions, init=None, num_envs=1, exact=0, impl=2, fuse_tail=0, upleg=0):
+    g = envmod.AFCEnv(num_envs=num_envs, resolution=res, reynolds=Re, exact_sums=exact, impl=impl, fuse_tail=fuse_tail,
+                      upleg=upleg)
     o = oracle_mod.Oracle(resolution=res, Re=Re)
     if init is not None:
         g.set_reset_state(init["u"], init["v"], init["p"])
@@ -267,6 +268,25 @@ def test_parity_mode_is_bit_exact(envmod, oracle_mod, init_bdim, res, Re, init, 
     assert np.array_equal(g.vorticity(), o.vorticity())
     assert np.array_equal(g.probes(32)[0], o.probes(32))
     _, rg = g.solver_stats()
+    g.close()
+
+
+@pytest.mark.parametrize("upleg", [1, 2, 3])
+@pytest.mark.parametrize("res,Re", [(8, 100), (16, 100)])
+def test_each_form_of_the_upleg_is_bit_exact(envmod, oracle_mod, res, Re, upleg):
+    """afc_config.upleg = 1 (strip pipeline, afc::prod), 2 (barrier form, afc::diag), 3 (march down the rows, afc::lat): each
+    kernel instantiation on its own against the oracle in parity mode -- MG.smooth's sweeps (MG.pde:79-92) in the reference's
+    order, so every float and every iteration count equals the oracle's (cold start: the first solves take several V-cycles,
+    the replay of the finest level included)."""
+    acts = [(0, 0)] * 3 + [(5.0, -5.0)] * 5 + [(-2.5, 1.0)] * 4
+    g, o, out = _run_pair(envmod, oracle_mod, res, Re, len(acts), acts, exact=1, upleg=upleg)
+    assert g.upleg() == upleg
+    for k, (fg, fo, itg, ito) in enumerate(out):
+        assert tuple(itg[0]) == tuple(ito), k
+        assert np.array_equal(fg[0], fo), (k, fg[0], fo)
+    ug, vg, pg = g.get_state()
+    uo, vo, po = o.get_state()
+    assert np.array_equal(ug, uo) and np.array_equal(vg, vo) and np.array_equal(pg, po)
     g.close()
 
 
