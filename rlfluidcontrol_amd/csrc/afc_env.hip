@@ -289,7 +289,7 @@ int sync_params(afc_env *env) {
 // the instantiation with the diagnostics compiled in runs only when one of them is switched on
 bool need_diag(const afc_env *env) {
   const StepParams &P = env->P;
-  return P.dbg != 0 || P.upleg == 2 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
+  return (AFC_EXP_STAMPS ? (P.dbg & ~8) != 0 : P.dbg != 0) || P.upleg == 2 || P.stagger_ticks > 0 || P.gate_limit != 0 || P.stamps != nullptr;
 }
 
 // 0 = shipped kernels, 1 = diagnostics compiled in, 2 = perf mode (red-black smoother; diagnostics are not available in it),

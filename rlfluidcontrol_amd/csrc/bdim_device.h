@@ -12,6 +12,11 @@
 // reductions (Field.sum for the mean pressure, Field.inner for the stopping test), which are tree
 // reductions by default and sequential (bit-identical step) when cfg.exact_sums is set.
 #pragma once
+// experiment builds (tools/build_variant.sh -DAFC_EXP_STAMPS=1): dbg = 8 (start-of-step-8 / end stamps in obs, tools/desync_probe.py)
+// is honoured by the SHIPPED instantiation instead of switching to the diagnostic one
+#ifndef AFC_EXP_STAMPS
+#define AFC_EXP_STAMPS 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

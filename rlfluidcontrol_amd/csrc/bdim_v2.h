@@ -7,16 +7,26 @@
 #pragma once
 #include "bdim_device.h"
 
+// AFC_PRIO: rotating base priorities of the workgroups that share a CU (prio_rotate in bdim_v2_body.h), every 2^AFC_PRIO
+// sim-steps of a launch; -1 = all at 0 (round 5).  Measured on the same memory, 1024 envs of 256x128, per launch:
+// 0: +0.5 .. -0.1 %, 1: -0.7 .. -1.5 % (eight boxes), 2: -0.2 .. -0.4 %; 128x64: -1.2 %.  afc::lat and afc::perf keep -1
+// (launches of few envs per CU have nothing to balance, and afc::lat's code answers any edit with +-0.5 %).
+#ifndef AFC_PRIO_ROT
+#define AFC_PRIO_ROT 1
+#endif
+
 // AFC_ONLY_MODE (0 / 1 / 2) restricts the header to one instantiation (the step-kernel translation units)
 #if !defined(AFC_ONLY_MODE) || AFC_ONLY_MODE == 0
 #define AFC_DIAG 0
 #define AFC_RB 0
 #define AFC_TR 0
+#define AFC_PRIO AFC_PRIO_ROT
 #define AFC_NS prod
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
 #undef AFC_TR
+#undef AFC_PRIO
 #undef AFC_NS
 #endif
 
@@ -29,11 +39,13 @@
 #define AFC_DIAG 0
 #define AFC_RB 0
 #define AFC_TR 1
+#define AFC_PRIO (-1)
 #define AFC_NS lat
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
 #undef AFC_TR
+#undef AFC_PRIO
 #undef AFC_NS
 #endif
 
@@ -41,11 +53,13 @@
 #define AFC_DIAG 1
 #define AFC_RB 0
 #define AFC_TR 1
+#define AFC_PRIO AFC_PRIO_ROT
 #define AFC_NS diag
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
 #undef AFC_TR
+#undef AFC_PRIO
 #undef AFC_NS
 #endif
 
@@ -56,10 +70,12 @@
 #define AFC_DIAG 0
 #define AFC_RB 1
 #define AFC_TR 0
+#define AFC_PRIO (-1)
 #define AFC_NS perf
 #include "bdim_v2_body.h"
 #undef AFC_DIAG
 #undef AFC_RB
 #undef AFC_TR
+#undef AFC_PRIO
 #undef AFC_NS
 #endif

@@ -112,6 +112,41 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)
 // table sits in global memory) occupy a VGPR each and get spilled around the register-hungry
 // loops; readfirstlane moves them to SGPRs.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Wave priorities.  Marches (serial chains: the critical path of their workgroup) run at 3.  Everything else ran at 0
+// through round 5 -- and among equal priorities the hardware issues the OLDEST wave first, so that the four workgroups of a
+// CU (b, b+256, b+512, b+768: dispatched in that order) drift 0.1 ms apart each, the first ahead (0.35 ms in the diagnostic
+// instantiation), and the last of them ends 0.7 ms (1.3 ms) after the first while the CU empties (tools/desync_probe.py).  AFC_PRIO >= 0 (bdim_v2.h: the shipped and the
+// diagnostic instantiation): the mates'
+// base priorities (0 .. 2) rotate every 2^AFC_PRIO sim-steps of a launch, so that every mate leads for a quarter of
+// it; a march saves the base (USER_PRIO of the STATUS register) and returns to it.  Only in the kernels of the grids of up
+// to 128 columns (k_agent_step<1 | 2, *>): the barrier-form up-legs of the wide grids lose 6 % per launch to ANY spread of
+// base priorities (512x256, 1024 envs: 91.6 -> 97.1 ms) -- a low mate's short all-thread stretches between two marches
+// then wait for every other workgroup of the CU.
+#undef AFC_PRIO_RAISE
+#undef AFC_PRIO_DROP
+#if AFC_PRIO >= 0
+__device__ __forceinline__ void prio_set(unsigned q) {
+  if (q == 0u) __builtin_amdgcn_s_setprio(0);
+  else if (q == 1u) __builtin_amdgcn_s_setprio(1);
+  else if (q == 2u) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+#define AFC_PRIO_RAISE() const unsigned prio0 = __builtin_amdgcn_s_getreg((1 << 11) | (3 << 6) | 2); /* hwreg(HW_REG_STATUS, 3, 2) = USER_PRIO */ \
+  __builtin_amdgcn_s_setprio(3)
+#define AFC_PRIO_DROP() prio_set(prio0)
+__device__ __forceinline__ void prio_rotate(int steps) {  // all waves, at the start of a sim-step of a launch
+  // only where four workgroups share a CU: with three (768 envs) the same rotation measured +0.2 .. +0.5 % per launch
+  if (gridDim.x > 768u) {
+    const unsigned k = (blockIdx.x >> 8) & 3u, s = (unsigned)uni(steps) >> AFC_PRIO;
+    const unsigned q = (k + s) & 3u;
+    prio_set(q > 2u ? 2u : q);  // base priorities 0 .. 2 (two mates tie): 3 stays the marches' alone
+  }
+}
+#else  // (the statements of round 5, verbatim: afc::lat's code answers any edit with +-0.5 % per launch)
+#define AFC_PRIO_RAISE() __builtin_amdgcn_s_setprio(3)
+#define AFC_PRIO_DROP() __builtin_amdgcn_s_setprio(0)
+#endif
+
 __device__ __forceinline__ float uni(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -1619,14 +1654,14 @@ __device__ AFC_UP_ATTR void mg_up_smooth(const bool HASC, const Lv &F, const Lv 
 #else
       const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
 #endif
-      __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
+      AFC_PRIO_RAISE();  // the serial march is the critical path of its workgroup
       if (special)
         gs_march3<false, true, H>(F, rr, dr, zrow, dummy, I0, &du);
       else if (du.zb)
         gs_march3<true, true, H>(F, rr, dr, zrow, dummy, I0, &du);
       else
         gs_march3<true, false, H>(F, rr, dr, zrow, dummy, I0, &du);
-      __builtin_amdgcn_s_setprio(0);
+      AFC_PRIO_DROP();
     }
     lds_barrier();
 #endif
@@ -1779,7 +1814,7 @@ __device__ AFC_UP_ATTR void mg_up_pipe(const bool HASC, const Lv &F, const Lv &C
     ps.mp = lds_addr((const float *)(lds_f *)(flags + tid));
     ps.ff = ff;
     ps.Q = Q;
-    __builtin_amdgcn_s_setprio(3);  // the serial march is the critical path of its workgroup
+    AFC_PRIO_RAISE();  // the serial march is the critical path of its workgroup
     int s = 0;
     for (int I0 = 1; I0 - 3 <= n_; I0 += H, ++s) {
       const bool special = (I0 + H >= du.sp_i0) && (I0 - 3 <= du.sp_i1);
@@ -1797,7 +1832,7 @@ __device__ AFC_UP_ATTR void mg_up_pipe(const bool HASC, const Lv &F, const Lv &C
       asm volatile("" ::: "memory");
       *(volatile lds_i *)(flags + tid) = (s + 1) << 10;  // strip s marched
     }
-    __builtin_amdgcn_s_setprio(0);
+    AFC_PRIO_DROP();
   } else {
     // (lane -> (row, chunk) with the chunk running fastest: four lanes read 64 contiguous bytes of a row.  With the ROW
     // running fastest the 128-bit LDS accesses would be free of bank conflicts -- rows are 12 (mod 32) banks apart -- and the
@@ -2901,9 +2936,9 @@ __device__ AFC_BOT_ATTR void mg_bottom(const StepParams &P, size_t e, int LB, fl
       pf.mark(16 + LB);
     }
     if (tid < 64) {
-      __builtin_amdgcn_s_setprio(3);  // a serial chain, like the march
+      AFC_PRIO_RAISE();  // a serial chain, like the march
       bottom_gs_wave(F);
-      __builtin_amdgcn_s_setprio(0);
+      AFC_PRIO_DROP();
     }
     lds_barrier();
     pf.mark(16 + LB + 1);

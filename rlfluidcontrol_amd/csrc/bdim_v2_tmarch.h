@@ -456,6 +456,8 @@ __device__ AFC_TR_ATTR TrOut mg_up_tr(const bool HASC_, const Lv F_, const Lv Cc
     A_.a_rr = lds_addr(rr), A_.a_z = lds_addr(zrow), A_.a_tab = lds_addr(tab), A_.a_apk = lds_addr(apk);
     A_.a_cF = lds_addr((const float *)(lds_f *)cF), A_.a_cM = lds_addr((const float *)(lds_f *)cM);
     A_.a_cB = lds_addr((const float *)(lds_f *)cB);
+    // (constant priorities here: this up-leg is picked for fewer than 2.5 workgroups per CU, where the base priorities do not
+    // rotate (prio_rotate) -- and the save / restore form moved afc::lat's launch by +0.5 %: see the note on the spin loops)
     __builtin_amdgcn_s_setprio(3);
     if (du.zb)
       tm_march<CB, true>(A_);

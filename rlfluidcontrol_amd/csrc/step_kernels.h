@@ -132,7 +132,14 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
   if constexpr (CPL >= 1 && (CPL <= 2 || AFC_FUSE_T2) && !DIAG) can_defer = afc::AFC_MODE_NS::heun_fusable<CPL>(P);
   while (steps < max_steps) {
     if (!(s.t < P.end_time)) break;  // clientCFD.pde:36
+#if AFC_EXP_STAMPS
+    if ((P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
+#else
     if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
+#endif
+#if (AFC_MODE == 0 || AFC_MODE == 1) && AFC_PRIO_ROT >= 0  // (afc::prod and afc::diag: AFC_PRIO in bdim_v2.h)
+    if constexpr (CPL == 1 || CPL == 2) afc::AFC_MODE_NS::prio_rotate(steps);  // (see prio_rotate: not for the wide grids)
+#endif
     bool defer = false;
     if (can_defer) {
       float t_after = s.t;
@@ -191,7 +198,11 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     reward[e] = -s.obs_cd - P.reward_penalty * (aa1 * aa1 * aa1 + aa2 * aa2 * aa2);  // server.py:61-65
     done[e] = (!(s.t < P.end_time)) ? 1 : 0;
     if (nsteps) nsteps[e] = steps;
+#if AFC_EXP_STAMPS
+    if (P.dbg & 8) {
+#else
     if (DIAG && (P.dbg & 8)) {  // diagnostic: wall-clock ticks (100 MHz, low 24 bits) at the start of step 8 and at the end
+#endif
       obs[2 * e] = (float)(dbg_t0 & 0xFFFFFF);
       obs[2 * e + 1] = (float)(wall_clock64() & 0xFFFFFF);
     }

@@ -20,3 +20,11 @@ for b in (0, 1, 8, 100):
 st = (obs[:, 0] - t0) % 167772.16
 en = (obs[:, 1] - t0) % 167772.16
 print("  step-8 start spread: min %.0f max %.0f std %.0f us; end: min %.0f max %.0f" % (st.min(), st.max(), st.std(), en.min(), en.max()))
+s4, e4 = st.reshape(4, 256), en.reshape(4, 256)  # [mate k][CU slot b]: env b + 256 k
+print("  mean over the 256 CU slots, by mate (dispatch order): step-8 start %s   end %s   (launch ends at %.0f)"
+      % (np.round(s4.mean(1), 0), np.round(e4.mean(1), 0), en.max()))
+print("  workgroup slots idle before the launch ends: %.0f us on average (the second half of the launch, steps 8-15, takes %.0f us)"
+      % ((en.max() - en).mean(), en.max() - st.min()))
+print("  end of the launch by XCD (env %% 8), mean over its 128 workgroups: %s" % np.round([en[x::8].mean() for x in range(8)], 0))
+cu_end = e4.max(0)  # when a CU slot's last mate ends
+print("  last mate of a CU slot ends: min %.0f  median %.0f  max %.0f" % (cu_end.min(), np.median(cu_end), cu_end.max()))

@@ -67,6 +67,20 @@ L=rlfluidcontrol_amd/libafc_env.so
 V=tools/bin/libafc_r6.so
 if [ -f $V ]; then SH="--share-slab"; else V=$L; SH=""; fi
 (for E in 1 64 256 512 640 768 1024; do python tools/ab_inproc.py $SH --envs $E --blocks 4 --per-block 4 $V:upleg=1 $V:upleg=3 $V 2>&1 | grep "ms per launch" | sed "s/^/E=$E  /"; done) > $O/${TAG}_launch_time_by_envs.txt
+# ---- rotating base priorities of the CU mates (round 6): this build against the same sources with -DAFC_PRIO_ROT=-1
+# (tools/bin/libafc_r5code.so: round 5's statements) on the same memory, and the mates' timeline inside a launch of the shipped
+# instantiation with and without them (-DAFC_EXP_STAMPS=1 builds: tools/bin/libafc_stamp0.so / libafc_stamp1.so) ----
+W=tools/bin/libafc_r5code.so
+if [ -f $V ] && [ -f $W ]; then
+  (for E in 1024 768 512 256; do echo "## 256x128, $E envs"; python tools/ab_inproc.py --share-slab --envs $E --blocks 8 --per-block 4 $W $V 2>&1 | grep "ms per launch"; done
+   echo "## 128x64, 1024 envs"; python tools/ab_inproc.py --share-slab --res 8 --blocks 8 --per-block 4 $W $V 2>&1 | grep "ms per launch"
+   echo "## 512x256 Re 400, 1024 envs (its kernels do not rotate)"; python tools/ab_inproc.py --share-slab --res 32 --reynolds 400 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch"
+   echo "## 384x192 Re 500, 1024 envs (its kernels do not rotate)"; python tools/ab_inproc.py --share-slab --res 24 --reynolds 500 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch") > $O/${TAG}_priority_rotation_ab.txt
+fi
+if [ -f tools/bin/libafc_stamp0.so ]; then
+  (for v in stamp0 stamp1; do echo "== the shipped instantiation, $v (0: all base priorities 0 as in round 5; 1: rotating)"; AFC_ENV_LIB=tools/bin/libafc_$v.so python tools/desync_probe.py 0 2>&1 | grep -v amdgpu.ids | tail -9; done
+   echo "== the diagnostic instantiation (rotating)"; python tools/desync_probe.py 0 2>&1 | grep -v amdgpu.ids | tail -5) > $O/${TAG}_cu_mates_timeline.txt
+fi
 # ---- one level's up-leg in isolation: barrier form | strip pipeline | march down the rows, bits and time; rows that cross a body ----
 (/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -Wno-unused-function -Iinclude -DAFC_TM_PROF=1 -o /tmp/ub tools/upleg_bench.hip 2>/dev/null && for a in "128 0 1 1 1" "64 1 0 0 1" "32 1 0 0 1"; do /tmp/ub $a; done) > $O/${TAG}_upleg_bench.txt 2>&1
 # ---- bench lines of a small batch (256 envs = one per CU): what ships there (the march down the rows) and the strip pipeline ----
