@@ -119,9 +119,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // diagnostic instantiation): the mates'
 // base priorities (0 .. 2) rotate every 2^AFC_PRIO sim-steps of a launch, so that every mate leads for a quarter of
 // it; a march saves the base (USER_PRIO of the STATUS register) and returns to it.  Only in the kernels of the grids of up
-// to 128 columns (k_agent_step<1 | 2, *>): the barrier-form up-legs of the wide grids lose 6 % per launch to ANY spread of
-// base priorities (512x256, 1024 envs: 91.6 -> 97.1 ms) -- a low mate's short all-thread stretches between two marches
-// then wait for every other workgroup of the CU.
+// to 128 columns (k_agent_step<1 | 2, *>): the wide grids' launches lose 6 % to this rotation (512x256, 1024 envs: 91.6 ->
+// 97.1 ms; a static pattern instead gave the one-tile grids -0.1 .. -0.5 % where the rotation gives -0.7 .. -1.5 %).
 #undef AFC_PRIO_RAISE
 #undef AFC_PRIO_DROP
 #if AFC_PRIO >= 0
@@ -142,6 +141,12 @@ __device__ __forceinline__ void prio_rotate(int steps) {  // all waves, at the s
     prio_set(q > 2u ? 2u : q);  // base priorities 0 .. 2 (two mates tie): 3 stays the marches' alone
   }
 }
+// The kernels of the 192-column grids (k_agent_step<3, *>: the reference's own 384x192 case): STATIC base priorities by mate,
+// 0 / 0 / 1 / 3 in dispatch order -- the youngest on top.  Same memory, 1024 envs, per launch: -2.9 % (two boxes; 0/0/2/3
+// -2.8 %, 0/0/1/2 -2.5 %, 0/1/2/3 -2.0 %, 0/1/1/3 -2.0 %, 0/0/0/3 -1.8 %, 0/0/0/1 -1.6 %, 0/0/1/1 -0.8 %, the oldest on top
+// +-0.0 %, rotating them as above +6 %); 768 / 512 envs -0.2 %.  The 256-column kernels (<4, *>) answer none of these
+// patterns by more than +-0.3 % and keep 0 for all.
+__device__ __forceinline__ void prio_by_mate() { prio_set((0x3100u >> (4u * ((blockIdx.x >> 8) & 3u))) & 3u); }
 #else  // (the statements of round 5, verbatim: afc::lat's code answers any edit with +-0.5 % per launch)
 #define AFC_PRIO_RAISE() __builtin_amdgcn_s_setprio(3)
 #define AFC_PRIO_DROP() __builtin_amdgcn_s_setprio(0)

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(afc::kThreads, 4) void k_agent_step(const StepParam
     if (DIAG && (P.dbg & 8) && steps == 8) dbg_t0 = wall_clock64();
 #endif
 #if (AFC_MODE == 0 || AFC_MODE == 1) && AFC_PRIO_ROT >= 0  // (afc::prod and afc::diag: AFC_PRIO in bdim_v2.h)
-    if constexpr (CPL == 1 || CPL == 2) afc::AFC_MODE_NS::prio_rotate(steps);  // (see prio_rotate: not for the wide grids)
+    if constexpr (CPL == 1 || CPL == 2) afc::AFC_MODE_NS::prio_rotate(steps);  // (not for the wide grids: see prio_rotate)
+    if constexpr (CPL == 3) afc::AFC_MODE_NS::prio_by_mate();  // 384x192: static priorities by mate
 #endif
     bool defer = false;
     if (can_defer) {

@@ -10,7 +10,8 @@ from rlfluidcontrol_amd import build, env  # noqa: E402
 build.build()
 stag = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
 E = 1024
-g = env.AFCEnv(num_envs=E, resolution=16, reynolds=100, stagger_us=stag, dbg=8)
+res = int(os.environ.get("RES", "16"))  # RES=32 RE=400: the 512x256 grid
+g = env.AFCEnv(num_envs=E, resolution=res, reynolds=int(os.environ.get("RE", "100")), stagger_us=stag, dbg=8)
 act = np.zeros((E, 2), np.float32)
 g.agent_step(act)
 obs = g.agent_step(act)[0].astype(np.float64) / 100.0  # us

@@ -67,15 +67,15 @@ L=rlfluidcontrol_amd/libafc_env.so
 V=tools/bin/libafc_r6.so
 if [ -f $V ]; then SH="--share-slab"; else V=$L; SH=""; fi
 (for E in 1 64 256 512 640 768 1024; do python tools/ab_inproc.py $SH --envs $E --blocks 4 --per-block 4 $V:upleg=1 $V:upleg=3 $V 2>&1 | grep "ms per launch" | sed "s/^/E=$E  /"; done) > $O/${TAG}_launch_time_by_envs.txt
-# ---- rotating base priorities of the CU mates (round 6): this build against the same sources with -DAFC_PRIO_ROT=-1
+# ---- base priorities of the CU mates (round 6: rotating in the one-tile kernels, static in the 192-column ones): this build against the same sources with -DAFC_PRIO_ROT=-1
 # (tools/bin/libafc_r5code.so: round 5's statements) on the same memory, and the mates' timeline inside a launch of the shipped
 # instantiation with and without them (-DAFC_EXP_STAMPS=1 builds: tools/bin/libafc_stamp0.so / libafc_stamp1.so) ----
 W=tools/bin/libafc_r5code.so
 if [ -f $V ] && [ -f $W ]; then
   (for E in 1024 768 512 256; do echo "## 256x128, $E envs"; python tools/ab_inproc.py --share-slab --envs $E --blocks 8 --per-block 4 $W $V 2>&1 | grep "ms per launch"; done
    echo "## 128x64, 1024 envs"; python tools/ab_inproc.py --share-slab --res 8 --blocks 8 --per-block 4 $W $V 2>&1 | grep "ms per launch"
-   echo "## 512x256 Re 400, 1024 envs (its kernels do not rotate)"; python tools/ab_inproc.py --share-slab --res 32 --reynolds 400 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch"
-   echo "## 384x192 Re 500, 1024 envs (its kernels do not rotate)"; python tools/ab_inproc.py --share-slab --res 24 --reynolds 500 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch") > $O/${TAG}_priority_rotation_ab.txt
+   echo "## 512x256 Re 400, 1024 envs (its kernels keep 0 for all)"; python tools/ab_inproc.py --share-slab --res 32 --reynolds 400 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch"
+   echo "## 384x192 Re 500, 1024 envs (its kernels: static 0 / 0 / 1 / 3 by mate)"; python tools/ab_inproc.py --share-slab --res 24 --reynolds 500 --blocks 5 --per-block 3 $W $V 2>&1 | grep "ms per launch") > $O/${TAG}_priority_rotation_ab.txt
 fi
 if [ -f tools/bin/libafc_stamp0.so ]; then
   (for v in stamp0 stamp1; do echo "== the shipped instantiation, $v (0: all base priorities 0 as in round 5; 1: rotating)"; AFC_ENV_LIB=tools/bin/libafc_$v.so python tools/desync_probe.py 0 2>&1 | grep -v amdgpu.ids | tail -9; done
