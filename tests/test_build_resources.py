@@ -62,6 +62,31 @@ def test_march_core_keeps_its_wait_states():
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(codeobj.LLVM, "clang-offload-bundler")) or shutil.which("objcopy") is None,
                     reason="ROCm LLVM tools not available")
+def test_base_priorities_are_where_they_were_measured():
+    """prio_rotate / prio_by_mate (bdim_v2_body.h): the shipped kernels of the one-tile grids (<1,0>, <2,0>) and of the
+    192-column grids (<3,0>) set base priorities 1 and 2 and read their base back (s_getreg_b32 of STATUS.USER_PRIO) around
+    every march; the 256-column kernels read it back but never set one (rotation +6 % there); afc::lat and afc::perf
+    (<*,3>, <*,2>) carry round 5's statements verbatim: s_setprio 3 / 0 only, no s_getreg."""
+    dis = codeobj.disassembly(build.build())
+
+    def prios(name):
+        text = codeobj.kernel_text(dis, name)
+        levels = {int(x.split()[1], 0) for x in text if x.startswith("s_setprio")}
+        return levels, sum(1 for x in text if x.startswith("s_getreg_b32") and "HW_REG_STATUS" in x)
+
+    for k in ("k_agent_stepILi1ELi0E", "k_agent_stepILi2ELi0E", "k_agent_stepILi3ELi0E"):
+        levels, reads = prios(k)
+        assert levels == {0, 1, 2, 3} and reads >= 2, (k, levels, reads)
+    levels, reads = prios("k_agent_stepILi4ELi0E")
+    assert reads >= 2, reads  # (its marches return to whatever the wave had: 0)
+    for k in ("k_agent_stepILi1ELi3E", "k_agent_stepILi2ELi3E", "k_agent_stepILi1ELi2E", "k_agent_stepILi2ELi2E"):
+        levels, reads = prios(k)
+        assert levels <= {0, 3} and reads == 0, (k, levels, reads)
+        assert levels == {0, 3} or k.endswith("Li2E"), (k, levels)  # (the red-black kernels have no serial stretch on most grids)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(codeobj.LLVM, "clang-offload-bundler")) or shutil.which("objcopy") is None,
+                    reason="ROCm LLVM tools not available")
 def test_every_lds_dma_sets_m0_right_in_front_of_itself():
     """lds_dma16 (bdim_v2_body.h) sets m0 inside inline assembly; LLVM ignores clobbers of reserved registers, so nothing
     but this check keeps a value the COMPILER put into m0 (it uses m0 for its own LDS-DMA copies, mg_bottom's table load)
